@@ -1,0 +1,181 @@
+// K2 generic path — C[M][N] = act(A[M][K] . W[N][K]^T + bias) for ANY M, N, K (fp32, gfx950), and the
+// layer-by-layer MLP driver ncf_mlp_forward built on it.
+//
+// LDS-tiled v_mfma_f32_32x32x2_f32 GEMM: workgroup tile 128 (M) x 64 (N), BK = 32, 4 waves each owning 32
+// rows x 64 columns (two 32x32 accumulators).  A and W tiles are staged through LDS with +4 float row padding
+// (row stride 36 floats: 16 consecutive rows start on 16 distinct 16-byte bank slots, so the ds_read_b128
+// operand reads are conflict-free).  Ragged edges (K = 2094, N = 1 ...) are zero-filled at staging time.
+// The K order inside each 8-wide group is permuted identically for both operands (lane half h takes k = 8g+4h+j),
+// which keeps every MFMA fed by one 16-byte LDS read per operand per 4 k-steps.
+// N <= 8 goes to a row-dot kernel (one 16-lane group per output element) instead of wasting a 64-wide tile.
+#include "ncf_common.h"
+
+namespace ncf {
+
+constexpr int BM = 128, BN = 64, BK = 32, LDT = BK + 4;
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ bias, float* __restrict__ C,
+                                                         int64_t ldc, int64_t M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Ws[BN * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        // stage A tile: 128 x 32 floats, 16 per thread, k fastest across lanes (coalesced 128-B row segments)
+#pragma unroll
+        for (int t = 0; t < (BM * BK) / 256; ++t) {
+            const int e = t * 256 + tid;
+            const int r = e >> 5, k = e & 31;
+            const int64_t gm = m0 + r;
+            const int gk = k0 + k;
+            As[r * LDT + k] = (gm < M && gk < K) ? A[gm * lda + gk] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < (BN * BK) / 256; ++t) {
+            const int e = t * 256 + tid;
+            const int r = e >> 5, k = e & 31;
+            const int gn = n0 + r;
+            const int gk = k0 + k;
+            Ws[r * LDT + k] = (gn < N && gk < K) ? W[(int64_t)gn * ldw + gk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&As[(32 * wave + i) * LDT + 8 * g + 4 * h]);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(&Ws[(i)*LDT + 8 * g + 4 * h]);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&Ws[(32 + i) * LDT + 8 * g + 4 * h]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], w0[j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], w1[j], acc[1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D[m][n]: column n = lane & 31, row m = acc_row(r, h)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int gn = n0 + 32 * t + i;
+        if (gn >= N) continue;
+        const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t gm = m0 + 32 * wave + acc_row(r, h);
+            if (gm < M) {
+                float v = acc[t][r] + bv;
+                if (RELU) v = fmaxf(v, 0.f);
+                C[gm * ldc + gn] = v;
+            }
+        }
+    }
+}
+
+// Small-N path: out[m][n] = act(bias[n] + sum_k A[m][k] * W[n][k]); one 16-lane group per (m, n).
+template <bool RELU>
+__global__ __launch_bounds__(256) void rowdot_f32_kernel(const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ bias, float* __restrict__ C,
+                                                         int64_t ldc, int64_t M, int N, int K) {
+    const int sub = threadIdx.x & 15;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int64_t total = M * N;
+    const int64_t total_pad = (total + 3) & ~int64_t(3);  // uniform trip count inside a wave (4 groups)
+    for (int64_t o = grp; o < total_pad; o += ngrp) {
+        float acc = 0.f;
+        const int64_t m = o / N;
+        const int n = (int)(o - m * N);
+        if (o < total) {
+            const float* a = A + m * lda;
+            const float* w = W + (int64_t)n * ldw;
+            for (int k = sub; k < K; k += 16) acc = fmaf(a[k], w[k], acc);
+        }
+        acc += __shfl_xor(acc, 8);
+        acc += __shfl_xor(acc, 4);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 1);
+        if (o < total && sub == 0) {
+            float v = acc + (bias ? bias[n] : 0.f);
+            if (RELU) v = fmaxf(v, 0.f);
+            C[m * ldc + n] = v;
+        }
+    }
+}
+
+static int launch_linear(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                         int64_t M, int N, int K, bool relu, hipStream_t s) {
+    if (M == 0) return NCF_OK;
+    if (N <= 8) {
+        int64_t blocks = (M * N + 15) / 16;
+        if (blocks > 16384) blocks = 16384;
+        if (relu) hipLaunchKernelGGL(rowdot_f32_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, N, K);
+        else hipLaunchKernelGGL(rowdot_f32_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    } else {
+        dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+        if (relu) hipLaunchKernelGGL(linear_f32_kernel<true>, grid, dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, N, K);
+        else hipLaunchKernelGGL(linear_f32_kernel<false>, grid, dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    }
+    return check_launch("linear_f32");
+}
+
+}  // namespace ncf
+
+using namespace ncf;
+
+static int max_hidden(int n_layers, const int* dims) {
+    int mx = 0;
+    for (int i = 1; i < n_layers; ++i) mx = dims[i] > mx ? dims[i] : mx;
+    return mx;
+}
+
+extern "C" size_t ncf_mlp_workspace_bytes(int dtype, int64_t B, int n_layers, const int* dims) {
+    if (dtype != NCF_F32 || !dims || n_layers < 1 || B < 0) return 0;
+    if (n_layers == 1) return 0;
+    const size_t per = (size_t)B * (size_t)max_hidden(n_layers, dims) * sizeof(float);
+    const size_t per_al = (per + 255) & ~size_t(255);
+    return n_layers == 2 ? per_al : 2 * per_al;
+}
+
+extern "C" int ncf_mlp_forward(int dtype, const void* x, int64_t B, int64_t ldx, int n_layers, const int* dims,
+                               const void* const* W, const void* const* b, void* workspace, size_t ws_bytes, void* out,
+                               int64_t ldOut, ncf_stream_t stream) {
+    if (dtype != NCF_F32) return fail(NCF_EUNSUPPORTED, "ncf_mlp_forward: fp32 only on the generic path");
+    if (B == 0) return NCF_OK;
+    if (!x || !dims || !W || !out || n_layers < 1 || B < 0) return fail(NCF_EINVAL, "ncf_mlp_forward: bad argument");
+    for (int i = 0; i <= n_layers; ++i)
+        if (dims[i] <= 0) return fail(NCF_EINVAL, "ncf_mlp_forward: dims[%d] = %d", i, dims[i]);
+    if (ldx < dims[0] || ldOut < dims[n_layers]) return fail(NCF_EINVAL, "ncf_mlp_forward: leading dimension smaller than row");
+    const size_t need = ncf_mlp_workspace_bytes(dtype, B, n_layers, dims);
+    if (need > 0 && (!workspace || ws_bytes < need)) return fail(NCF_EWORKSPACE, "ncf_mlp_forward: workspace %zu < %zu bytes", ws_bytes, need);
+    if (B == 0) return NCF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int mh = max_hidden(n_layers, dims);
+    const size_t per_al = (((size_t)B * mh * sizeof(float)) + 255) & ~size_t(255);
+    float* buf[2] = {(float*)workspace, (float*)((char*)workspace + per_al)};
+    const float* in = (const float*)x;
+    int64_t ldin = ldx;
+    for (int i = 0; i < n_layers; ++i) {
+        if (!W[i]) return fail(NCF_EINVAL, "ncf_mlp_forward: W[%d] is null", i);
+        const bool last = i == n_layers - 1;
+        float* o = last ? (float*)out : buf[i & 1];
+        const int64_t ldo = last ? ldOut : dims[i + 1];
+        const int rc = launch_linear(in, ldin, (const float*)W[i], dims[i], b ? (const float*)b[i] : nullptr, o, ldo, B,
+                                     dims[i + 1], dims[i], !last, s);
+        if (rc != NCF_OK) return rc;
+        in = o;
+        ldin = ldo;
+    }
+    return NCF_OK;
+}

@@ -1,0 +1,290 @@
+// K1+K2 fused — gather -> concat -> MLP -> (B,1) in one launch, fp32, gfx950.
+//
+// Design (one wave = one tile of 32 pairs, no LDS, no inter-wave communication):
+//   Every layer is computed TRANSPOSED:  H^T[n][m] = W[n][:] . X^T[:][m]  with the pair index m on the MFMA
+//   column (= lane & 31) and the neuron index n on the accumulator rows (registers).  With
+//   v_mfma_f32_32x32x2_f32 the C/D register r of lane-half h holds row (r&3) + 8(r>>2) + 4h, and the B operand
+//   of the *next* layer wants B[k = step + h][m] on the same lane — so register r of the previous layer's
+//   accumulator IS the next layer's B operand for k-step r (after bias + ReLU).  Activations never leave
+//   registers between layers; only weights stream in.
+//   Weights are pre-packed (ncf_mlp_pack) as Wp[q][nt][lane][4] = W[32nt + (lane&31)][8q + 4(lane>>5) + 0..3],
+//   so one 16-byte load per lane feeds 4 consecutive MFMAs and a wave-instruction reads 1 KiB contiguous.
+//   The layer-1 B operand is the gathered embedding row itself: lane (m, h) reads the 16-byte chunk 2q + h of
+//   pair m's concatenated row straight from the tables (each 128-B line is consumed by 4 consecutive loads).
+//   The K order inside an 8-wide group is permuted identically for A and B, which only changes the fp32
+//   summation order (exact FMA chain, one rounding per product).
+// Bound: fp32 MFMA (157.3 TFLOP/s).  FLOP per pair = 2 * (K0*N1 + N1*N2 + N2)  (131 328 at 128-256-128-1).
+#include "ncf_common.h"
+
+namespace ncf {
+
+struct FusedArgs {
+    const float* tabA; int64_t rowsA; int64_t ldA;
+    const float* tabB; int64_t rowsB; int64_t ldB;
+    const int64_t* idxA; const int64_t* idxB;
+    int64_t B; int EA;
+    const float* Wp1; const float* b1;
+    const float* Wp2; const float* b2;
+    const float* wl; const float* bl;   // last (1-wide) layer: weights [Nlast], bias [1]
+    float* out; int32_t* oob;
+};
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int K0, int N1, int N2>
+__global__ __launch_bounds__(256, 2) void score_fused_f32_kernel(FusedArgs a) {
+    constexpr int NT1 = N1 / 32, Q1 = K0 / 8;
+    constexpr int NT2 = N2 / 32, Q2 = N1 / 8;
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 32 >= a.B) return;  // whole wave exits together
+    const int64_t p = tile * 32 + m;
+    const int64_t pc = p < a.B ? p : a.B - 1;
+
+    // ---- gather setup: row pointers of this lane's pair ----
+    const int64_t ia = a.idxA ? a.idxA[pc] : pc;
+    const bool okA = (ia >= 0) & (ia < a.rowsA);
+    const float* rowA = a.tabA + (okA ? ia : 0) * a.ldA + 4 * h;
+    const int qa = a.EA / 8;  // groups served by table A
+    const float* rowB = rowA;
+    bool okB = true;
+    if (qa < Q1) {
+        const int64_t ib = a.idxB ? a.idxB[pc] : pc;
+        okB = (ib >= 0) & (ib < a.rowsB);
+        rowB = a.tabB + (okB ? ib : 0) * a.ldB + 4 * h;
+    }
+    if (!(okA & okB) && a.oob) *a.oob = 1;
+    const float zA = okA ? 1.f : 0.f, zB = okB ? 1.f : 0.f;  // out-of-range rows read as zeros
+
+    // ---- layer 1: acc1 = b1 (broadcast over pairs) + W1 . X^T ----
+    f32x16 acc1[NT1];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bb = ldg4(a.b1 + 32 * nt + 8 * g + 4 * h);
+            acc1[nt][4 * g + 0] = bb[0]; acc1[nt][4 * g + 1] = bb[1];
+            acc1[nt][4 * g + 2] = bb[2]; acc1[nt][4 * g + 3] = bb[3];
+        }
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp1) + lane;  // + (q*NT1 + nt)*64
+        f32x4 w[2][NT1];
+        f32x4 x[2];
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) w[0][nt] = wp[nt * 64];
+        x[0] = ldg4(0 < qa ? rowA : rowB);
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) {
+            const int cur = q & 1, nxt = cur ^ 1;
+            if (q + 1 < Q1) {
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt) w[nxt][nt] = wp[((q + 1) * NT1 + nt) * 64];
+                const bool fromA = q + 1 < qa;  // wave-uniform: EA % 8 == 0
+                x[nxt] = ldg4(fromA ? rowA + 8 * (q + 1) : rowB + 8 * (q + 1 - qa));
+            }
+            // pin the prefetch ABOVE this step's MFMAs: without it hipcc sinks each load to just before its use
+            // (load -> vmcnt(0) -> 4 MFMAs ...), exposing the L2 latency 8 times per step.
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 xb = x[cur] * (q < qa ? zA : zB);  // zero an out-of-range row at USE time (keeps the load un-waited)
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], xb[j], acc1[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    float partial = 0.f;
+    if constexpr (N2 > 0) {
+        // ---- layer 2: acc2 = b2 + W2 . relu(acc1) ; acc1 registers are the B operands ----
+        f32x16 acc2[NT2];
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = ldg4(a.b2 + 32 * nt + 8 * g + 4 * h);
+                acc2[nt][4 * g + 0] = bb[0]; acc2[nt][4 * g + 1] = bb[1];
+                acc2[nt][4 * g + 2] = bb[2]; acc2[nt][4 * g + 3] = bb[3];
+            }
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp2) + lane;
+        f32x4 w[2][NT2];
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) w[0][nt] = wp[nt * 64];
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) {  // q = 4*kb + g : k-block kb of H1 (= tile kb of acc1), group g
+            const int cur = q & 1, nxt = cur ^ 1;
+            const int kb = q >> 2, g = q & 3;
+            if (q + 1 < Q2) {
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt) w[nxt][nt] = wp[((q + 1) * NT2 + nt) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float hv = fmaxf(acc1[kb][4 * g + j], 0.f);  // ReLU (util.py:15)
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt)
+                    acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], hv, acc2[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- last layer (1 wide): out = bl + sum_n wl[n] * relu(acc2[n]) ----
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ww = ldg4(a.wl + 32 * nt + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) partial = fmaf(ww[j], fmaxf(acc2[nt][4 * g + j], 0.f), partial);
+            }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ww = ldg4(a.wl + 32 * nt + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) partial = fmaf(ww[j], fmaxf(acc1[nt][4 * g + j], 0.f), partial);
+            }
+    }
+    partial += __shfl_xor(partial, 32);  // the two lane halves hold complementary neuron rows
+    if (h == 0 && p < a.B) a.out[p] = partial + a.bl[0];
+}
+
+// Pack W [N][K] row-major into Wp[q][nt][lane][4].
+__global__ void pack_weight_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ Wp) {
+    const int64_t total = (int64_t)N * K;
+    const int NT = N / 32;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(o & 3);
+        const int lane = (int)((o >> 2) & 63);
+        const int64_t t = o >> 8;  // q*NT + nt
+        const int nt = (int)(t % NT), q = (int)(t / NT);
+        Wp[o] = W[(int64_t)(32 * nt + (lane & 31)) * K + 8 * q + 4 * (lane >> 5) + j];
+    }
+}
+
+__global__ void copy_or_zero_kernel(const float* __restrict__ src, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src ? src[i] : 0.f;
+}
+
+// blob layout (floats): Wp1[N1*K0] b1[N1] (Wp2[N2*N1] b2[N2])? wl[Nlast] bl[1] pad
+struct BlobLayout {
+    size_t wp1, b1, wp2, b2, wl, bl, total;
+};
+static BlobLayout blob_layout(const int* dims, int n_layers) {
+    BlobLayout L{};
+    const size_t K0 = dims[0], N1 = dims[1];
+    size_t off = 0;
+    L.wp1 = off; off += N1 * K0;
+    L.b1 = off; off += N1;
+    size_t last = N1;
+    if (n_layers == 3) {
+        const size_t N2 = dims[2];
+        L.wp2 = off; off += N2 * N1;
+        L.b2 = off; off += N2;
+        last = N2;
+    }
+    L.wl = off; off += last;
+    L.bl = off; off += 4;  // keep 16-byte granularity
+    L.total = off;
+    return L;
+}
+
+typedef void (*fused_fn)(FusedArgs);
+template <int K0, int N1, int N2>
+static void launch_inst(const FusedArgs& a, hipStream_t s) {
+    const int64_t tiles = (a.B + 31) / 32;
+    const unsigned blocks = (unsigned)((tiles + 3) / 4);
+    hipLaunchKernelGGL((score_fused_f32_kernel<K0, N1, N2>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+#define NCF_FUSED_INSTANCES(X) \
+    X(64, 256, 128) X(64, 256, 0) X(64, 128, 0) X(64, 128, 64) \
+    X(128, 256, 128) X(128, 256, 0) X(128, 128, 0) X(128, 128, 64) \
+    X(256, 256, 128) X(256, 256, 0) X(256, 128, 0)
+
+static bool fused_dispatch(int K0, int N1, int N2, const FusedArgs* a, hipStream_t s) {
+#define X(k, n1, n2) \
+    if (K0 == k && N1 == n1 && N2 == n2) { if (a) launch_inst<k, n1, n2>(*a, s); return true; }
+    NCF_FUSED_INSTANCES(X)
+#undef X
+    return false;
+}
+
+static bool fused_shape_ok(int dtype, int EA, int EB, int n_layers, const int* dims) {
+    if (dtype != NCF_F32 || !dims) return false;
+    if (n_layers != 2 && n_layers != 3) return false;
+    if (dims[n_layers] != 1) return false;
+    if (EA <= 0 || EB < 0 || EA % 8 || EB % 8 || EA + EB != dims[0]) return false;
+    return fused_dispatch(dims[0], dims[1], n_layers == 3 ? dims[2] : 0, nullptr, nullptr);
+}
+
+}  // namespace ncf
+
+using namespace ncf;
+
+extern "C" int ncf_score_fused_supported(int dtype, int EA, int EB, int n_layers, const int* dims) {
+    return fused_shape_ok(dtype, EA, EB, n_layers, dims) ? 1 : 0;
+}
+
+extern "C" size_t ncf_mlp_packed_bytes(int dtype, int n_layers, const int* dims) {
+    if (dtype != NCF_F32 || !dims || (n_layers != 2 && n_layers != 3)) return 0;
+    return blob_layout(dims, n_layers).total * sizeof(float);
+}
+
+extern "C" int ncf_mlp_pack(int dtype, int n_layers, const int* dims, const void* const* W, const void* const* b,
+                            void* packed, size_t packed_bytes, ncf_stream_t stream) {
+    if (dtype != NCF_F32) return fail(NCF_EUNSUPPORTED, "ncf_mlp_pack: fp32 only");
+    if (!dims || !W || !packed || (n_layers != 2 && n_layers != 3)) return fail(NCF_EINVAL, "ncf_mlp_pack: bad argument");
+    if (dims[n_layers] != 1) return fail(NCF_EUNSUPPORTED, "ncf_mlp_pack: last layer must be 1 wide");
+    for (int i = 0; i < n_layers; ++i) {
+        if (!W[i]) return fail(NCF_EINVAL, "ncf_mlp_pack: W[%d] is null", i);
+        if (i < n_layers - 1 && (dims[i] % 8 || dims[i + 1] % 32))
+            return fail(NCF_EUNSUPPORTED, "ncf_mlp_pack: layer %d dims (%d -> %d) not tileable (K %% 8, N %% 32)", i, dims[i], dims[i + 1]);
+    }
+    const BlobLayout L = blob_layout(dims, n_layers);
+    if (packed_bytes < L.total * sizeof(float)) return fail(NCF_EWORKSPACE, "ncf_mlp_pack: packed buffer too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* P = (float*)packed;
+    auto bias = [&](int i) { return b ? (const float*)b[i] : nullptr; };
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(256), dim3(256), 0, s, (const float*)W[0], dims[1], dims[0], P + L.wp1);
+    hipLaunchKernelGGL(copy_or_zero_kernel, dim3((dims[1] + 255) / 256), dim3(256), 0, s, bias(0), dims[1], P + L.b1);
+    int last = dims[1];
+    if (n_layers == 3) {
+        hipLaunchKernelGGL(pack_weight_kernel, dim3(256), dim3(256), 0, s, (const float*)W[1], dims[2], dims[1], P + L.wp2);
+        hipLaunchKernelGGL(copy_or_zero_kernel, dim3((dims[2] + 255) / 256), dim3(256), 0, s, bias(1), dims[2], P + L.b2);
+        last = dims[2];
+    }
+    hipLaunchKernelGGL(copy_or_zero_kernel, dim3((last + 255) / 256), dim3(256), 0, s, (const float*)W[n_layers - 1], last, P + L.wl);
+    hipLaunchKernelGGL(copy_or_zero_kernel, dim3(1), dim3(256), 0, s, bias(n_layers - 1), 1, P + L.bl);
+    return check_launch("ncf_mlp_pack");
+}
+
+extern "C" int ncf_score_fused(int dtype, const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, int64_t rowsB,
+                               int64_t ldB, const int64_t* idxA, const int64_t* idxB, int64_t B, int EA, int EB,
+                               int n_layers, const int* dims, const void* packed, float* out, int32_t* oob,
+                               ncf_stream_t stream) {
+    if (!fused_shape_ok(dtype, EA, EB, n_layers, dims))
+        return fail(NCF_EUNSUPPORTED, "ncf_score_fused: no specialised kernel for dtype=%d EA=%d EB=%d layers=%d", dtype, EA, EB, n_layers);
+    if (B == 0) return NCF_OK;
+    if (B < 0 || !tabA || (EB > 0 && !tabB) || !packed || !out) return fail(NCF_EINVAL, "ncf_score_fused: bad argument");
+    if (ldA < EA || (EB > 0 && ldB < EB) || ldA % 4 || (EB > 0 && ldB % 4) || !aligned16(tabA) || (EB > 0 && !aligned16(tabB)) || !aligned16(packed))
+        return fail(NCF_EINVAL, "ncf_score_fused: tables must be 16-byte aligned with ld %% 4 == 0");
+    if (B == 0) return NCF_OK;
+    const BlobLayout L = blob_layout(dims, n_layers);
+    const float* P = (const float*)packed;
+    FusedArgs a;
+    a.tabA = (const float*)tabA; a.rowsA = rowsA; a.ldA = ldA;
+    a.tabB = (const float*)(EB ? tabB : tabA); a.rowsB = EB ? rowsB : rowsA; a.ldB = EB ? ldB : ldA;
+    a.idxA = idxA; a.idxB = idxB; a.B = B; a.EA = EA;
+    a.Wp1 = P + L.wp1; a.b1 = P + L.b1;
+    a.Wp2 = n_layers == 3 ? P + L.wp2 : nullptr; a.b2 = n_layers == 3 ? P + L.b2 : nullptr;
+    a.wl = P + L.wl; a.bl = P + L.bl;
+    a.out = out; a.oob = oob;
+    fused_dispatch(dims[0], dims[1], n_layers == 3 ? dims[2] : 0, &a, (hipStream_t)stream);
+    return check_launch("ncf_score_fused");
+}

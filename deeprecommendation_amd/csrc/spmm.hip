@@ -1,0 +1,213 @@
+// K4/K5 — LightGCN propagation: CSR-by-destination SpMM as a wavefront segmented reduction (fp32, gfx950).
+//
+// HBM-bound row gather: per directed edge D*4 bytes of source row + 4 (col) + 4 (coef).  One wave owns one
+// SEGMENT (a contiguous edge range of one destination row).  LPR = D/4 lanes (rounded up to a power of two)
+// cover one source row with 16-byte loads, so a wave-instruction reads 64/LPR whole contiguous rows; 4 such
+// instructions are kept in flight per lane.  The 64/LPR partial sums are combined with cross-lane shuffles.
+// Load balance: destination rows longer than the caller's segment length are split into several segments
+// (`row_of` maps segment -> destination); their partial sums go to `partial` and a second kernel adds them in
+// segment order.  No float atomics anywhere: the result is bitwise reproducible run to run.
+// The layer-mean accumulator (gnn_ncf.py:351) is fused into the epilogue: sum[row] += y[row].
+#include "ncf_common.h"
+
+namespace ncf {
+
+template <int LPR>
+__device__ __forceinline__ f32x4 reduce_groups(f32x4 v) {
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        v[0] += __shfl_xor(v[0], off);
+        v[1] += __shfl_xor(v[1], off);
+        v[2] += __shfl_xor(v[2], off);
+        v[3] += __shfl_xor(v[3], off);
+    }
+    return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_seg_kernel(const int64_t* __restrict__ segptr, const int32_t* __restrict__ row_of,
+                                                       int64_t n_seg, const int32_t* __restrict__ col,
+                                                       const float* __restrict__ coef, const float* __restrict__ z,
+                                                       int64_t Nz, int64_t ldz, int chunks, float* __restrict__ y,
+                                                       int64_t ldy, float* __restrict__ sum, int64_t ldsum,
+                                                       float* __restrict__ partial) {
+    constexpr int EPI = 64 / LPR;  // edges per wave-instruction
+    constexpr int UNROLL = 4;
+    const int lane = threadIdx.x & 63;
+    const int c = lane % LPR;       // 16-byte chunk of the row this lane owns
+    const int eg = lane / LPR;      // which of the EPI concurrent edges
+    const bool active = c < chunks;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t s = wave0; s < n_seg; s += nwaves) {
+        const int64_t beg = segptr[s], end = segptr[s + 1];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t e0 = beg; e0 < end; e0 += EPI * UNROLL) {
+            f32x4 v[UNROLL];
+            float w[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t e = e0 + u * EPI + eg;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                w[u] = 0.f;
+                if (e < end && active) {
+                    const int64_t src = col[e];
+                    if (src >= 0 && src < Nz) {
+                        w[u] = coef ? coef[e] : 1.f;
+                        v[u] = *reinterpret_cast<const f32x4*>(z + src * ldz + 4 * c);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                acc[0] = fmaf(w[u], v[u][0], acc[0]);
+                acc[1] = fmaf(w[u], v[u][1], acc[1]);
+                acc[2] = fmaf(w[u], v[u][2], acc[2]);
+                acc[3] = fmaf(w[u], v[u][3], acc[3]);
+            }
+        }
+        acc = reduce_groups<LPR>(acc);
+        if (eg == 0 && active) {
+            const int64_t row = row_of ? row_of[s] : s;
+            const bool first = !row_of || s == 0 || row_of[s - 1] != row;
+            const bool last = !row_of || s == n_seg - 1 || row_of[s + 1] != row;
+            if (first && last) {
+                *reinterpret_cast<f32x4*>(y + row * ldy + 4 * c) = acc;
+                if (sum) {
+                    f32x4* sp = reinterpret_cast<f32x4*>(sum + row * ldsum + 4 * c);
+                    *sp = *sp + acc;
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(partial + s * (int64_t)(4 * chunks) + 4 * c) = acc;
+            }
+        }
+    }
+}
+
+// Adds the partial sums of rows that were split over several segments, in segment order.
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_fix_kernel(const int32_t* __restrict__ row_of, int64_t n_seg, int chunks,
+                                                       const float* __restrict__ partial, float* __restrict__ y,
+                                                       int64_t ldy, float* __restrict__ sum, int64_t ldsum) {
+    const int c = threadIdx.x % LPR;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+    const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) / LPR;
+    for (int64_t s = grp; s < n_seg; s += ngrp) {
+        const int32_t row = row_of[s];
+        const bool first = s == 0 || row_of[s - 1] != row;
+        const bool last = s == n_seg - 1 || row_of[s + 1] != row;
+        if (!first || last || c >= chunks) continue;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t t = s; t < n_seg && row_of[t] == row; ++t)
+            acc = acc + *reinterpret_cast<const f32x4*>(partial + t * (int64_t)(4 * chunks) + 4 * c);
+        *reinterpret_cast<f32x4*>(y + (int64_t)row * ldy + 4 * c) = acc;
+        if (sum) {
+            f32x4* sp = reinterpret_cast<f32x4*>(sum + (int64_t)row * ldsum + 4 * c);
+            *sp = *sp + acc;
+        }
+    }
+}
+
+__global__ void degree_kernel(const int64_t* __restrict__ dst, int64_t E, int64_t N, float* __restrict__ deg, int32_t* oob) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = dst[e];
+        if (d >= 0 && d < N) atomicAdd(deg + d, 1.0f);  // exact: counts stay below 2^24
+        else if (oob) *oob = 1;
+    }
+}
+
+__device__ __forceinline__ float inv_sqrt_or_zero(float d) {
+    // deg.pow(-0.5) with inf -> 0 (gnn_ncf.py:49-50); torch's pow(-0.5) is 1 / sqrt(x)
+    return d > 0.f ? 1.0f / sqrtf(d) : 0.f;
+}
+
+__global__ void edge_coef_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                 const float* __restrict__ attr, const float* __restrict__ deg, int64_t E, int64_t N,
+                                 float* __restrict__ coef) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = src[e], d = dst[e];
+        float norm = 0.f;
+        if (s >= 0 && s < N && d >= 0 && d < N) norm = inv_sqrt_or_zero(deg[s]) * inv_sqrt_or_zero(deg[d]);  // :54/:58/:66
+        coef[e] = attr ? attr[e] * norm : norm;  // (weight * norm) * W(x_j), :91 / :93
+    }
+}
+
+__global__ void scale_rows_kernel(const float* __restrict__ in, int64_t ldin, int64_t N, int D, float divisor,
+                                  float* __restrict__ out, int64_t ldout) {
+    const int64_t total = N * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / D;
+        const int d = (int)(i - n * D);
+        out[n * ldout + d] = in[n * ldin + d] / divisor;  // torch.mean = sum / n
+    }
+}
+
+template <int LPR>
+static void launch_spmm(const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col, const float* coef,
+                        const float* z, int64_t Nz, int64_t ldz, int chunks, float* y, int64_t ldy, float* sum, int64_t ldsum,
+                        float* partial, hipStream_t s) {
+    int64_t blocks = (n_seg + 3) / 4;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL((spmm_seg_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, s, segptr, row_of, n_seg, col, coef, z, Nz,
+                       ldz, chunks, y, ldy, sum, ldsum, partial);
+    if (row_of) {
+        int64_t fb = (n_seg * LPR + 255) / 256;
+        if (fb > 256 * 64) fb = 256 * 64;
+        hipLaunchKernelGGL((spmm_fix_kernel<LPR>), dim3((unsigned)fb), dim3(256), 0, s, row_of, n_seg, chunks, partial, y, ldy, sum, ldsum);
+    }
+}
+
+}  // namespace ncf
+
+using namespace ncf;
+
+extern "C" int ncf_spmm_csr(int dtype, const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col,
+                            const float* coef, const void* z, int64_t Nz, int64_t ldz, int D, void* y, int64_t ldy,
+                            float* sum, int64_t ldsum, float* partial, ncf_stream_t stream) {
+    if (dtype != NCF_F32) return fail(NCF_EUNSUPPORTED, "ncf_spmm_csr: fp32 only");
+    if (!segptr || !z || !y || n_seg < 0 || D <= 0) return fail(NCF_EINVAL, "ncf_spmm_csr: bad argument");
+    if (D % 4 || D > 256) return fail(NCF_EUNSUPPORTED, "ncf_spmm_csr: D = %d (need D %% 4 == 0 and D <= 256)", D);
+    if (ldz % 4 || ldy % 4 || (sum && ldsum % 4) || !aligned16(z) || !aligned16(y) || (sum && !aligned16(sum)) || (partial && !aligned16(partial)))
+        return fail(NCF_EINVAL, "ncf_spmm_csr: rows must be 16-byte aligned (ld %% 4 == 0)");
+    if (row_of && !partial) return fail(NCF_EINVAL, "ncf_spmm_csr: split rows need a partial buffer");
+    if (n_seg == 0) return NCF_OK;
+    if (!col) return fail(NCF_EINVAL, "ncf_spmm_csr: col is null");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = D / 4;
+    const float* zf = (const float*)z;
+    float* yf = (float*)y;
+    if (chunks <= 8) launch_spmm<8>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, s);
+    else if (chunks <= 16) launch_spmm<16>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, s);
+    else if (chunks <= 32) launch_spmm<32>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, s);
+    else launch_spmm<64>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, s);
+    return check_launch("ncf_spmm_csr");
+}
+
+extern "C" int ncf_degree_accumulate(const int64_t* dst, int64_t E, int64_t N, float* deg, int32_t* oob, ncf_stream_t stream) {
+    if (E < 0 || N < 0 || (E > 0 && (!dst || !deg))) return fail(NCF_EINVAL, "ncf_degree_accumulate: bad argument");
+    if (E == 0) return NCF_OK;
+    int64_t blocks = (E + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(degree_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dst, E, N, deg, oob);
+    return check_launch("ncf_degree_accumulate");
+}
+
+extern "C" int ncf_edge_coef(const int64_t* src, const int64_t* dst, const float* attr, const float* deg, int64_t E, int64_t N,
+                             float* coef, ncf_stream_t stream) {
+    if (E < 0 || N < 0 || (E > 0 && (!src || !dst || !deg || !coef))) return fail(NCF_EINVAL, "ncf_edge_coef: bad argument");
+    if (E == 0) return NCF_OK;
+    int64_t blocks = (E + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(edge_coef_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, attr, deg, E, N, coef);
+    return check_launch("ncf_edge_coef");
+}
+
+extern "C" int ncf_scale_rows(const float* in, int64_t ldin, int64_t N, int D, float divisor, float* out, int64_t ldout,
+                              ncf_stream_t stream) {
+    if (N < 0 || D <= 0 || (N > 0 && (!in || !out))) return fail(NCF_EINVAL, "ncf_scale_rows: bad argument");
+    if (N == 0) return NCF_OK;
+    int64_t blocks = (N * D + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, ldin, N, D, divisor, out, ldout);
+    return check_launch("ncf_scale_rows");
+}

@@ -1,0 +1,329 @@
+"""ctypes binding of libncf_hip.so (include/ncf_abi.h) + thin torch-tensor marshalling.
+
+PyTorch is used for device memory and streams only: every function here takes CUDA(=HIP) tensors, passes raw
+device pointers + sizes + the current HIP stream to the C ABI and returns tensors it allocated for the result.
+There is NO fallback: if the shared library is missing or a tensor is not on a GPU, these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libncf_hip.so")
+
+NCF_F32, NCF_BF16 = 0, 1
+NCF_OK, NCF_EINVAL, NCF_EUNSUPPORTED, NCF_ELAUNCH, NCF_EWORKSPACE = 0, -1, -2, -3, -4
+ATT_MLP, ATT_LINEAR, ATT_COS = 0, 1, 2
+
+_c_i64 = ctypes.c_int64
+_c_p = ctypes.c_void_p
+_c_int = ctypes.c_int
+_c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); the parity tests check that every symbol declared in include/ncf_abi.h is here
+# and exported by the library.
+SIGNATURES = {
+    "ncf_version": (_c_int, []),
+    "ncf_last_error": (ctypes.c_char_p, []),
+    "ncf_build_arch": (ctypes.c_char_p, []),
+    "ncf_gather_concat": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int,
+                                   _c_p, _c_i64, _c_p, _c_p]),
+    "ncf_gather_dot": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p]),
+    "ncf_mlp_workspace_bytes": (_c_size, [_c_int, _c_i64, _c_int, _c_p]),
+    "ncf_mlp_forward": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_i64, _c_p]),
+    "ncf_score_fused_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_p]),
+    "ncf_mlp_packed_bytes": (_c_size, [_c_int, _c_int, _c_p]),
+    "ncf_mlp_pack": (_c_int, [_c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p]),
+    "ncf_score_fused": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int,
+                                 _c_int, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "ncf_spmm_csr": (_c_int, [_c_int, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p,
+                              _c_i64, _c_p, _c_p]),
+    "ncf_degree_accumulate": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
+    "ncf_edge_coef": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "ncf_scale_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, ctypes.c_float, _c_p, _c_i64, _c_p]),
+    "ncf_attn_forward": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
+                                  _c_i64, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libncf_hip: {msg} (status {code})")
+        self.code = code
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen the HIP library and bind every ABI symbol.  Raises if it is absent — there is no CPU path."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(needs hipcc). deeprecommendation_amd has no CPU fallback.")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != NCF_OK:
+        raise NativeError(rc, load_library().ncf_last_error().decode())
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live on the GPU (got {t.device}); deeprecommendation_amd has no CPU path")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return NCF_F32
+    if t.dtype == torch.bfloat16:
+        return NCF_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _rows2d(t: torch.Tensor, what: str):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{what} must be 2-D with unit inner stride")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def _idx(t: Optional[torch.Tensor], B: Optional[int] = None):
+    if t is None:
+        return None
+    if t.dtype != torch.int64 or t.dim() != 1 or not t.is_contiguous():
+        raise ValueError("index tensors must be contiguous 1-D int64")
+    return t
+
+
+_oob_flags = {}
+
+
+def _oob_flag(device) -> torch.Tensor:
+    f = _oob_flags.get(device)
+    if f is None:
+        f = torch.zeros(1, dtype=torch.int32, device=device)
+        _oob_flags[device] = f
+    return f
+
+
+def check_oob(device):
+    """Synchronising check of the sticky out-of-range flag (torch indexing raises IndexError in the reference)."""
+    f = _oob_flag(device)
+    if int(f.item()) != 0:
+        f.zero_()
+        raise IndexError("index out of range in an embedding gather")
+
+
+# ------------------------------------------------------------------ K1
+def gather_concat(tabA: torch.Tensor, idxA: Optional[torch.Tensor], tabB: Optional[torch.Tensor] = None,
+                  idxB: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, B: Optional[int] = None):
+    lib = load_library()
+    _dev(tabA, "tabA")
+    rowsA, EA, ldA = _rows2d(tabA, "tabA")
+    rowsB = EB = ldB = 0
+    if tabB is not None:
+        _dev(tabB, "tabB")
+        rowsB, EB, ldB = _rows2d(tabB, "tabB")
+        if tabB.dtype != tabA.dtype:
+            raise TypeError("tables must share a dtype")
+    idxA, idxB = _idx(idxA), _idx(idxB)
+    if B is None:
+        B = idxA.numel() if idxA is not None else (idxB.numel() if idxB is not None else rowsA)
+    if out is None:
+        out = torch.empty((B, EA + EB), dtype=tabA.dtype, device=tabA.device)
+    _, _, ldo = _rows2d(out, "out")
+    _check(lib.ncf_gather_concat(_dt(tabA), _ptr(tabA), rowsA, ldA, _ptr(tabB), rowsB, ldB, _ptr(idxA), _ptr(idxB), B, EA, EB,
+                                 _ptr(out), ldo, _ptr(_oob_flag(tabA.device)), _stream(tabA)))
+    return out
+
+
+def gather_dot(tabA: torch.Tensor, idxA, tabB: torch.Tensor, idxB, B: Optional[int] = None):
+    lib = load_library()
+    _dev(tabA, "tabA"), _dev(tabB, "tabB")
+    rowsA, EA, ldA = _rows2d(tabA, "tabA")
+    rowsB, EB, ldB = _rows2d(tabB, "tabB")
+    if EA != EB or tabA.dtype != tabB.dtype:
+        raise ValueError("gather_dot needs equal widths and dtypes")
+    idxA, idxB = _idx(idxA), _idx(idxB)
+    if B is None:
+        B = idxA.numel() if idxA is not None else idxB.numel()
+    out = torch.empty((B, 1), dtype=torch.float32, device=tabA.device)
+    _check(lib.ncf_gather_dot(_dt(tabA), _ptr(tabA), rowsA, ldA, _ptr(tabB), rowsB, ldB, _ptr(idxA), _ptr(idxB), B, EA,
+                              _ptr(out), _ptr(_oob_flag(tabA.device)), _stream(tabA)))
+    return out
+
+
+# ------------------------------------------------------------------ K2 generic
+def _dims_array(dims: Sequence[int]):
+    return (ctypes.c_int * len(dims))(*[int(d) for d in dims])
+
+
+def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def mlp_forward(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act chain: Linear, (ReLU, Linear)* — no activation after the last layer.  Any dims, fp32."""
+    lib = load_library()
+    _dev(x, "x")
+    B, K0, ldx = _rows2d(x, "x")
+    dims = [K0] + [int(w.shape[0]) for w in weights]
+    for i, w in enumerate(weights):
+        _dev(w, "weight")
+        if w.dtype != torch.float32 or not w.is_contiguous() or w.shape[1] != dims[i]:
+            raise ValueError(f"weight {i} must be contiguous fp32 [{dims[i + 1]}, {dims[i]}]")
+    biases = [None if b is None else b.contiguous() for b in biases]
+    n = len(weights)
+    d = _dims_array(dims)
+    ws_bytes = lib.ncf_mlp_workspace_bytes(NCF_F32, B, n, d)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+    if out is None:
+        out = torch.empty((B, dims[-1]), dtype=torch.float32, device=x.device)
+    _, _, ldo = _rows2d(out, "out")
+    _check(lib.ncf_mlp_forward(NCF_F32, _ptr(x), B, ldx, n, d, _ptr_array(weights), _ptr_array(biases), _ptr(ws), ws_bytes,
+                               _ptr(out), ldo, _stream(x)))
+    return out
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, out=None) -> torch.Tensor:
+    return mlp_forward(x, [weight], [bias], out=out)
+
+
+# ------------------------------------------------------------------ K1+K2 fused
+class PackedMLP:
+    """Weights of an MLP ending in a 1-wide layer, pre-packed for ncf_score_fused (built once per model)."""
+
+    def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+        lib = load_library()
+        self.dims = [int(weights[0].shape[1])] + [int(w.shape[0]) for w in weights]
+        self.n_layers = len(weights)
+        self.device = weights[0].device
+        d = _dims_array(self.dims)
+        nbytes = lib.ncf_mlp_packed_bytes(NCF_F32, self.n_layers, d)
+        if nbytes == 0:
+            raise NativeError(NCF_EUNSUPPORTED, "MLP shape cannot be packed for the fused kernel")
+        ws = [w.detach().to(torch.float32).contiguous() for w in weights]
+        bs = [None if b is None else b.detach().to(torch.float32).contiguous() for b in biases]
+        for w in ws:
+            _dev(w, "weight")
+        self.blob = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        _check(lib.ncf_mlp_pack(NCF_F32, self.n_layers, d, _ptr_array(ws), _ptr_array(bs), _ptr(self.blob), nbytes,
+                                _stream(ws[0])))
+
+    def supports(self, EA: int, EB: int) -> bool:
+        return bool(load_library().ncf_score_fused_supported(NCF_F32, EA, EB, self.n_layers, _dims_array(self.dims)))
+
+
+def fused_supported(EA: int, EB: int, dims: Sequence[int]) -> bool:
+    return bool(load_library().ncf_score_fused_supported(NCF_F32, EA, EB, len(dims) - 1, _dims_array(dims)))
+
+
+def score_fused(tabA: torch.Tensor, idxA, tabB: Optional[torch.Tensor], idxB, packed: PackedMLP,
+                out: Optional[torch.Tensor] = None, B: Optional[int] = None) -> torch.Tensor:
+    lib = load_library()
+    _dev(tabA, "tabA")
+    rowsA, EA, ldA = _rows2d(tabA, "tabA")
+    rowsB = EB = ldB = 0
+    if tabB is not None:
+        _dev(tabB, "tabB")
+        rowsB, EB, ldB = _rows2d(tabB, "tabB")
+    idxA, idxB = _idx(idxA), _idx(idxB)
+    if B is None:
+        B = idxA.numel() if idxA is not None else (idxB.numel() if idxB is not None else rowsA)
+    if out is None:
+        out = torch.empty((B, 1), dtype=torch.float32, device=tabA.device)
+    _check(lib.ncf_score_fused(_dt(tabA), _ptr(tabA), rowsA, ldA, _ptr(tabB), rowsB, ldB, _ptr(idxA), _ptr(idxB), B, EA, EB,
+                               packed.n_layers, _dims_array(packed.dims), _ptr(packed.blob), _ptr(out),
+                               _ptr(_oob_flag(tabA.device)), _stream(tabA)))
+    return out
+
+
+# ------------------------------------------------------------------ K4 / K5
+def spmm_csr(segptr: torch.Tensor, row_of: Optional[torch.Tensor], col: torch.Tensor, coef: Optional[torch.Tensor],
+             z: torch.Tensor, N: int, y: Optional[torch.Tensor] = None, acc_sum: Optional[torch.Tensor] = None,
+             partial: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = load_library()
+    _dev(z, "z")
+    Nz, D, ldz = _rows2d(z, "z")
+    n_seg = segptr.numel() - 1
+    if segptr.dtype != torch.int64 or col.dtype != torch.int32:
+        raise TypeError("segptr must be int64 and col int32")
+    if row_of is not None and row_of.dtype != torch.int32:
+        raise TypeError("row_of must be int32")
+    if y is None:
+        y = torch.empty((N, D), dtype=torch.float32, device=z.device)
+    if row_of is not None and partial is None:
+        partial = torch.empty((n_seg, D), dtype=torch.float32, device=z.device)
+    _check(lib.ncf_spmm_csr(NCF_F32, _ptr(segptr), _ptr(row_of), n_seg, _ptr(col), _ptr(coef), _ptr(z), Nz, ldz, D, _ptr(y),
+                            y.stride(0), _ptr(acc_sum), 0 if acc_sum is None else acc_sum.stride(0), _ptr(partial), _stream(z)))
+    return y
+
+
+def degree_accumulate(dst: torch.Tensor, N: int, deg: torch.Tensor):
+    lib = load_library()
+    _dev(dst, "dst")
+    _check(lib.ncf_degree_accumulate(_ptr(dst), dst.numel(), N, _ptr(deg), _ptr(_oob_flag(dst.device)), _stream(dst)))
+    return deg
+
+
+def edge_coef(src: torch.Tensor, dst: torch.Tensor, attr: Optional[torch.Tensor], deg: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    _dev(src, "src")
+    coef = torch.empty(src.numel(), dtype=torch.float32, device=src.device)
+    _check(lib.ncf_edge_coef(_ptr(src), _ptr(dst), _ptr(attr), _ptr(deg), src.numel(), deg.numel(), _ptr(coef), _stream(src)))
+    return coef
+
+
+def scale_rows(x: torch.Tensor, divisor: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = load_library()
+    _dev(x, "x")
+    N, D, ld = _rows2d(x, "x")
+    if out is None:
+        out = torch.empty((N, D), dtype=torch.float32, device=x.device)
+    _check(lib.ncf_scale_rows(_ptr(x), ld, N, D, float(divisor), _ptr(out), out.stride(0), _stream(x)))
+    return out
+
+
+# ------------------------------------------------------------------ K3
+def attn_forward(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[torch.Tensor], b1: float,
+                 rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, feat: torch.Tensor,
+                 out_bias: Optional[torch.Tensor] = None):
+    """Returns (out_feat (B, Fdim), weights (nnz,))."""
+    lib = load_library()
+    _dev(pc, "pc")
+    B, A, ldpc = _rows2d(pc, "pc")
+    I, A2, ldpr = _rows2d(pr, "pr")
+    I2, Fdim, ldf = _rows2d(feat, "feat")
+    if A != A2 or I != I2:
+        raise ValueError("attention operand shapes disagree")
+    if rowptr.dtype != torch.int64 or col.dtype != torch.int32 or val.dtype != torch.float32:
+        raise TypeError("CSR must be (int64 rowptr, int32 col, fp32 val)")
+    out = torch.empty((B, Fdim), dtype=torch.float32, device=pc.device)
+    wts = torch.empty(max(col.numel(), 1), dtype=torch.float32, device=pc.device)
+    _check(lib.ncf_attn_forward(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), float(b1), _ptr(rowptr), _ptr(col), _ptr(val),
+                                B, I, _ptr(feat), ldf, Fdim, _ptr(out_bias), _ptr(out), out.stride(0), _ptr(wts), _stream(pc)))
+    return out, wts[:col.numel()]

@@ -1,0 +1,99 @@
+"""BasicNCF — drop-in for reference models/basic_ncf.py (same ctor kwargs, state_dict keys, forward signature).
+
+forward(X_user, X_item) dispatches on the input:
+  * int64 (B,) positions  -> table path: T = W^T + b per side (the reference's Linear over a one-hot row,
+    basic_ncf.py:38-39 with src/util.py:5-10), gathered and scored by ONE fused HIP kernel (ncf_score_fused);
+  * float (B, dim) rows   -> dense path: the two Linears as HIP GEMMs, then the same fused MLP kernel on the
+    (B, E) activations (identity gather).
+Both run only on CUDA(HIP) tensors in eval / no-grad mode; a training step uses the differentiable torch ops.
+"""
+import torch
+from torch import nn
+
+from ... import native
+from ..util import build_MLP_layers, mlp_linears, params_version, require_gpu, use_native
+from .base import NCF
+
+
+class _ScoringMixin:
+    """Derived inference tensors shared by BasicNCF / MF / GraphNCF: embedding tables and packed MLP weights."""
+
+    def _refresh(self):
+        ver = params_version(self)
+        if getattr(self, "_native_ver", None) != ver:
+            self._native_cache = {}
+            self._native_ver = ver
+        return self._native_cache
+
+    def _table(self, name: str, lin: nn.Linear) -> torch.Tensor:
+        cache = self._refresh()
+        if name not in cache:
+            with torch.no_grad():
+                # row i = W[:, i] + b : exactly what Linear(onehot(i)) computes (one fp32 rounding)
+                cache[name] = (lin.weight.detach().t().contiguous() + lin.bias.detach()).contiguous()
+        return cache[name]
+
+    def _packed_mlp(self, name: str = "MLP"):
+        cache = self._refresh()
+        key = "packed::" + name
+        if key not in cache:
+            lins = mlp_linears(getattr(self, name))
+            try:
+                cache[key] = native.PackedMLP([l.weight for l in lins], [l.bias for l in lins])
+            except native.NativeError as e:
+                if e.code != native.NCF_EUNSUPPORTED:
+                    raise
+                cache[key] = None
+        return cache[key]
+
+    def _score(self, tabA, idxA, tabB, idxB, mlp_name="MLP"):
+        """gather(A) ‖ gather(B) -> MLP -> (B,1): fused kernel when the shape has an instance, else K1 + K2."""
+        packed = self._packed_mlp(mlp_name)
+        EA = tabA.shape[1]
+        EB = 0 if tabB is None else tabB.shape[1]
+        if packed is not None and packed.supports(EA, EB):
+            return native.score_fused(tabA, idxA, tabB, idxB, packed)
+        x = native.gather_concat(tabA, idxA, tabB, idxB)
+        lins = mlp_linears(getattr(self, mlp_name))
+        return native.mlp_forward(x, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
+
+
+class BasicNCF(_ScoringMixin, NCF):
+    compatible_datasets = ("FixedPointwiseDataset", "FixedRankingDataset")
+
+    def __init__(self, item_dim, user_dim, dropout_rate=0.2, item_emb=256, user_emb=256, mlp_dense_layers=None):
+        super().__init__()
+        if mlp_dense_layers is None:
+            mlp_dense_layers = [256, 128]
+        self.kwargs = {'item_dim': item_dim, 'user_dim': user_dim, 'item_emb': item_emb, 'user_emb': user_emb,
+                       'mlp_dense_layers': mlp_dense_layers, 'dropout_rate': dropout_rate}
+        self.item_embeddings = nn.Sequential(nn.Linear(item_dim, item_emb))
+        self.user_embeddings = nn.Sequential(nn.Linear(user_dim, user_emb))
+        self.MLP = build_MLP_layers(item_emb + user_emb, mlp_dense_layers, dropout_rate=dropout_rate)
+
+    def get_model_parameters(self) -> dict:
+        return self.kwargs
+
+    def forward(self, X_user, X_item):
+        indexed = X_user.dtype == torch.int64 and X_user.dim() == 1
+        if not use_native(self):
+            return self._forward_train(X_user, X_item, indexed)
+        require_gpu(X_user, X_item)
+        if indexed:
+            return self._score(self._table("user", self.user_embeddings[0]), X_user.contiguous(),
+                               self._table("item", self.item_embeddings[0]), X_item.contiguous())
+        ue, ie = self.user_embeddings[0], self.item_embeddings[0]
+        u = native.linear(X_user.float().contiguous(), ue.weight.detach(), ue.bias.detach())
+        i = native.linear(X_item.float().contiguous(), ie.weight.detach(), ie.bias.detach())
+        return self._score(u, None, i, None)  # cat(user, item): basic_ncf.py:40
+
+    def _forward_train(self, X_user, X_item, indexed):
+        """Differentiable torch path for a training step (dropout active, autograd recording)."""
+        if indexed:
+            ue, ie = self.user_embeddings[0], self.item_embeddings[0]
+            user_emb = ue.weight.t()[X_user] + ue.bias
+            item_emb = ie.weight.t()[X_item] + ie.bias
+        else:
+            user_emb = self.user_embeddings(X_user)
+            item_emb = self.item_embeddings(X_item)
+        return self.MLP(torch.cat((user_emb, item_emb), dim=1))

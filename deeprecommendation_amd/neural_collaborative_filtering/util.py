@@ -1,0 +1,61 @@
+"""Host-side mirror of the reference's ``neural_collaborative_filtering/util.py`` (MLP topology + checkpoint I/O)."""
+import torch
+from torch import nn
+
+
+def build_MLP_layers(input_size, layer_sizes: list, dropout_rate, output_size=1) -> nn.Sequential:
+    """Same module layout as reference util.py:5-18 so state_dict keys match (MLP.0, MLP.3, ... with dropout;
+    MLP.0, MLP.2, ... when ``dropout_rate is None``): Linear, then (ReLU, [Dropout], Linear) per further layer,
+    the last Linear being ``output_size`` wide with no activation after it."""
+    widths = list(layer_sizes) + [output_size]
+    mods = [nn.Linear(input_size, widths[0])]
+    for prev, cur in zip(widths[:-1], widths[1:]):
+        mods.append(nn.ReLU())
+        if dropout_rate is not None:
+            mods.append(nn.Dropout(dropout_rate))
+        mods.append(nn.Linear(prev, cur))
+    return nn.Sequential(*mods)
+
+
+def mlp_linears(seq: nn.Sequential):
+    """The Linear modules of a build_MLP_layers Sequential, in order."""
+    return [m for m in seq if isinstance(m, nn.Linear)]
+
+
+def load_model(file, ModelClass=None, map_location="cpu", **kargs):
+    """Reads a reference checkpoint ``[state_dict, kwargs]`` (reference models/base.py:18-19, util.py:21-34).
+
+    Unlike the reference this passes ``map_location`` (its shipped checkpoints were saved from CUDA tensors and
+    cannot be opened on a CPU-only host otherwise) and ``weights_only=True`` (nothing in the file is executed).
+    """
+    state, kwargs = torch.load(file, map_location=map_location, weights_only=True)
+    kwargs = dict(kwargs, **kargs)
+    if ModelClass is None:
+        return state, kwargs
+    model = ModelClass(**kwargs)
+    model.load_state_dict(state)
+    return model
+
+
+def params_version(module: nn.Module) -> tuple:
+    """Cheap fingerprint of a module's parameters: changes whenever a parameter is updated in place, re-assigned
+    or moved.  Used to invalidate the derived inference tensors (embedding tables, packed MLP weights)."""
+    return tuple((p.data_ptr(), p._version, str(p.device)) for p in module.parameters())
+
+
+def use_native(module: nn.Module, *tensors) -> bool:
+    """The HIP kernels implement the *scoring* forward.  They run when the module is in eval mode and autograd is
+    not recording; a training step (module.training or grad enabled with trainable parameters) keeps to the
+    differentiable torch ops, as SURVEY.md §8(a9) scopes it."""
+    if module.training:
+        return False
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        return False
+    return True
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("deeprecommendation_amd scores on an MI355X only: inputs must be CUDA(HIP) tensors "
+                               f"(got {t.device}). There is no CPU fallback.")

@@ -1,0 +1,194 @@
+/*
+ * ncf_abi.h — C ABI of libncf_hip.so, the MI355X (gfx950) hot path of the NCF scoring forward.
+ *
+ * The reference (michaelbzms/DeepRecommendation) is 100 % Python on PyTorch; it has no FFI, no custom
+ * operator and no native code.  The "interface each entry point replaces" is therefore the sequence of
+ * ATen ops a reference forward() issues; each declaration below cites it as
+ * src/neural_collaborative_filtering/<file>:<line> of the reference.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - return 0 (NCF_OK) or a negative ncf_status; never throw.  ncf_last_error() returns a thread-local
+ *     human-readable message for the last failure on the calling thread.
+ *   - every pointer named dev_* / documented "device" is a HIP device pointer owned by the caller; the
+ *     library never allocates persistent device memory, never synchronises the stream, never copies to the
+ *     host.  Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *   - index arrays are int64 at the ABI (the reference uses torch.long: datasets/gnn_datasets.py:28);
+ *     CSR column ids are int32 (node counts < 2^31).
+ *   - leading dimensions (ld*) are in ELEMENTS of the tensor's dtype.
+ *   - re-entrant: no global mutable state besides the thread-local error string.
+ *   - out-of-range indices never fault: the offending row is read as zeros and, when `dev_oob_flag` is
+ *     non-NULL, *dev_oob_flag is set to 1 (the host wrapper turns that into IndexError on request, which is
+ *     what torch indexing raises in the reference).
+ */
+#ifndef NCF_ABI_H
+#define NCF_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NCF_ABI_VERSION 1
+
+typedef void* ncf_stream_t; /* hipStream_t */
+
+enum ncf_dtype { NCF_F32 = 0, NCF_BF16 = 1 };
+
+enum ncf_status {
+    NCF_OK = 0,
+    NCF_EINVAL = -1,       /* bad argument (null pointer, negative size, misaligned, inconsistent dims) */
+    NCF_EUNSUPPORTED = -2, /* shape/dtype has no specialised kernel: caller should take the unfused entry points */
+    NCF_ELAUNCH = -3,      /* HIP reported an error at launch */
+    NCF_EWORKSPACE = -4    /* workspace too small */
+};
+
+int ncf_version(void);
+const char* ncf_last_error(void);
+/* Architecture the device code was compiled for ("gfx950"). */
+const char* ncf_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  embedding gather (+ fused concat)
+ * Replaces: nn.Linear applied to one-hot rows + torch.cat — models/basic_ncf.py:38-40, models/mf.py:29-30;
+ *           combined_graph_emb[itemIds] / [userIds] + cat — models/gnn_ncf.py:354-361.
+ * out[p, 0:EA] = tabA[idxA[p], 0:EA];  out[p, EA:EA+EB] = tabB[idxB[p], 0:EB]     (bit-exact copy)
+ * tabB/idxB may be NULL with EB = 0 (single-table gather).  idxA / idxB may be NULL = identity (row p).
+ * ------------------------------------------------------------------------------------------------ */
+int ncf_gather_concat(int dtype,
+                      const void* dev_tabA, int64_t rowsA, int64_t ldA,
+                      const void* dev_tabB, int64_t rowsB, int64_t ldB,
+                      const int64_t* dev_idxA, const int64_t* dev_idxB,
+                      int64_t B, int EA, int EB,
+                      void* dev_out, int64_t ldOut,
+                      int32_t* dev_oob_flag, ncf_stream_t stream);
+
+/* Row-wise dot product of two gathered rows, out[p] = sum_e tabA[idxA[p], e] * tabB[idxB[p], e]  (fp32
+ * accumulate, fp32 out).  Replaces: torch.bmm(user_emb.unsqueeze(1), item_emb.unsqueeze(2)) —
+ * models/mf.py:31, models/gnn_ncf.py:365. */
+int ncf_gather_dot(int dtype,
+                   const void* dev_tabA, int64_t rowsA, int64_t ldA,
+                   const void* dev_tabB, int64_t rowsB, int64_t ldB,
+                   const int64_t* dev_idxA, const int64_t* dev_idxB,
+                   int64_t B, int E, float* dev_out,
+                   int32_t* dev_oob_flag, ncf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  MLP forward, generic layer-by-layer path (any dims)
+ * Replaces: nn.Sequential(Linear, [ReLU, Dropout(eval = identity), Linear]*) — util.py:5-18, called at
+ *           models/basic_ncf.py:41, models/attention_ncf.py:179,222, models/gnn_ncf.py:362; and single
+ *           nn.Linear layers (n_layers = 1): models/attention_ncf.py:150-151,216, models/gnn_ncf.py:300-301,
+ *           the hoisted per-node form of gnn_ncf.py:91-93.
+ * dims[0] = input width, dims[i] = out_features of layer i (i = 1..n_layers).  W[i] is device [dims[i+1]][dims[i]]
+ * row-major (torch nn.Linear.weight layout), b[i] is device [dims[i+1]] (may be NULL = no bias).
+ * ReLU is applied between layers, never after the last one.  Intermediates live in `dev_workspace`
+ * (ncf_mlp_workspace_bytes).  fp32 only on this entry (NCF_F32); accumulation is an exact fp32 FMA chain
+ * (v_mfma_f32_32x32x2_f32).
+ * `host_W` / `host_b` are HOST arrays of DEVICE pointers.
+ * ------------------------------------------------------------------------------------------------ */
+size_t ncf_mlp_workspace_bytes(int dtype, int64_t B, int n_layers, const int* dims);
+int ncf_mlp_forward(int dtype, const void* dev_x, int64_t B, int64_t ldx,
+                    int n_layers, const int* dims,
+                    const void* const* host_W, const void* const* host_b,
+                    void* dev_workspace, size_t workspace_bytes,
+                    void* dev_out, int64_t ldOut, ncf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1+K2 fused: gather -> concat -> MLP -> (B,1) without the (B, EA+EB) round trip through HBM.
+ * Replaces the whole of models/basic_ncf.py:37-42 (table form) and models/gnn_ncf.py:354-362.
+ *
+ * The MLP must end in a 1-wide layer (util.py:10 output_size = 1): dims = {EA+EB, h1, [h2,] 1}.
+ * Weights are passed PRE-PACKED (ncf_mlp_pack) in the lane order the MFMA operands are consumed in, so a
+ * wave streams them with fully coalesced 16-byte loads; pack once per model, reuse for every batch.
+ * Returns NCF_EUNSUPPORTED when (dtype, EA, EB, dims) has no specialised instance — use
+ * ncf_gather_concat + ncf_mlp_forward then.  ncf_score_fused_supported() answers without launching.
+ * idxA / idxB NULL = identity, so a dense activation matrix x (B, K0) can be scored with tabA = x, EB = 0.
+ * ------------------------------------------------------------------------------------------------ */
+int ncf_score_fused_supported(int dtype, int EA, int EB, int n_layers, const int* dims);
+size_t ncf_mlp_packed_bytes(int dtype, int n_layers, const int* dims);
+int ncf_mlp_pack(int dtype, int n_layers, const int* dims,
+                 const void* const* host_W, const void* const* host_b,
+                 void* dev_packed, size_t packed_bytes, ncf_stream_t stream);
+int ncf_score_fused(int dtype,
+                    const void* dev_tabA, int64_t rowsA, int64_t ldA,
+                    const void* dev_tabB, int64_t rowsB, int64_t ldB,
+                    const int64_t* dev_idxA, const int64_t* dev_idxB,
+                    int64_t B, int EA, int EB,
+                    int n_layers, const int* dims, const void* dev_packed,
+                    float* dev_out, int32_t* dev_oob_flag, ncf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4/K5  LightGCN propagation as CSR-by-destination SpMM with a wavefront segmented reduction
+ * Replaces: PyG MessagePassing.propagate(aggr='add') + message() — models/gnn_ncf.py:52-70,74-94
+ *           (per-edge Linear hoisted to a per-node Linear, which is ncf_mlp_forward with n_layers = 1),
+ *           torch_geometric.utils.degree + deg.pow(-0.5) — gnn_ncf.py:47-50,
+ *           torch.mean(torch.stack(hs)) — gnn_ncf.py:351 (running sum fused into the SpMM epilogue).
+ *
+ * Segment s owns edges [segptr[s], segptr[s+1]) and belongs to destination row row_of[s] (row_of == NULL:
+ * row s, i.e. segptr is a plain CSR rowptr).  Long rows may be split by the caller into several CONSECUTIVE
+ * segments (load balance under Zipf-skewed degrees); their partial sums are added in segment order, so
+ *   y[n, :] = sum over the segments of row n, in order, of  sum_{e in segment} coef[e] * z[col[e], :]
+ * is bitwise reproducible (no float atomics).  Every row must own at least one (possibly empty) segment.
+ * if dev_sum != NULL:  dev_sum[n, :] += y[n, :]   (layer-sum accumulator for the final mean)
+ * z is (Nz, D) with leading dimension ldz; y and sum are (N, D).  D % 4 == 0, D <= 256.
+ * coef may be NULL (all ones).  dev_partial: (n_seg, D) floats scratch, required when dev_row_of != NULL.
+ * ------------------------------------------------------------------------------------------------ */
+int ncf_spmm_csr(int dtype, const int64_t* dev_segptr, const int32_t* dev_row_of, int64_t n_seg,
+                 const int32_t* dev_col, const float* dev_coef,
+                 const void* dev_z, int64_t Nz, int64_t ldz, int D,
+                 void* dev_y, int64_t ldy, float* dev_sum, int64_t ldsum,
+                 float* dev_partial, ncf_stream_t stream);
+
+/* deg[n] = number of edges whose destination is n (float, exact below 2^24) — PyG degree(), gnn_ncf.py:48.
+ * dev_deg must be zero-filled by the caller; two calls (u2i, i2u) accumulate into the same array, which is
+ * the cat at gnn_ncf.py:41. */
+int ncf_degree_accumulate(const int64_t* dev_dst, int64_t E, int64_t N, float* dev_deg,
+                          int32_t* dev_oob_flag, ncf_stream_t stream);
+/* coef[e] = (attr ? attr[e] : 1) * (dis[src[e]] * dis[dst[e]]),  dis = deg^-1/2 with inf -> 0
+ * (gnn_ncf.py:49-50,54,58,66 and the product order of :91 / :93). */
+int ncf_edge_coef(const int64_t* dev_src, const int64_t* dev_dst, const float* dev_attr,
+                  const float* dev_deg, int64_t E, int64_t N, float* dev_coef, ncf_stream_t stream);
+/* out[n, :] = in[n, :] / divisor  (the division of torch.mean over the L+1 stacked layers, gnn_ncf.py:351). */
+int ncf_scale_rows(const float* dev_in, int64_t ldin, int64_t N, int D, float divisor,
+                   float* dev_out, int64_t ldout, ncf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  AttentionNCF item-item attention: scores -> masked row softmax -> rating-weighted aggregation
+ * Replaces models/attention_ncf.py:154-213 (eval mode).  Inputs are the *projected* operands:
+ *   att_dense > 0 (AttentionNet = Linear(2·IE -> A), ReLU, Linear(A -> 1), :112-117):
+ *       dev_pc (B, A)   = cand_emb  @ W0[:, :IE]^T + b0        (candidate half of AttentionNet.0, bias folded)
+ *       dev_pr (I, A)   = rated_emb @ W0[:, IE:]^T            (rated half)
+ *       score(b, i)     = b1 + sum_a w1[a] * relu(pc[b, a] + pr[i, a])
+ *     which is AttentionNet(cat(cand, rated)) with the first Linear split at the concat boundary (:176).
+ *   att_dense == 0 (AttentionNet = Linear(2·IE -> 1), :120-122): A = 1, no ReLU:
+ *       score(b, i) = pc[b, 0] + pr[i, 0]
+ *   cosine (:162-173): dev_pc / dev_pr are the L2-normalised embeddings (B, IE) / (I, IE), mode = NCF_ATT_COS,
+ *       score = dot.
+ * The user's rated set is CSR: row b owns entries [rowptr[b], rowptr[b+1]) with col = position in the rated
+ * list (0..I-1) and val = the non-zero user_matrix entry (:158 `user_matrix != 0`).
+ *   w = softmax over the row's entries (empty row -> all zeros, :208-209)
+ *   dev_out_feat[b, :] = bias + sum_i  w[b,i] * val[b,i] * feat[col_i, :]      (:212-213), feat is (I, Fdim)
+ *     feat may be the raw item features (Fdim = F; bias NULL; UserEmbeddings applied afterwards, :216) or, using
+ *     the linearity of UserEmbeddings over the weighted sum, the pre-projected rows feat = rated_items @ Wu^T
+ *     (Fdim = UE) with dev_out_bias = bu — then dev_out_feat IS user_embeddings of :216.
+ *   dev_weights ((nnz,) floats aligned with the CSR entries, REQUIRED: it doubles as the score scratch) receives
+ *     the attention weights w (what return_attention_weights exposes, :224).
+ * ------------------------------------------------------------------------------------------------ */
+enum ncf_att_mode { NCF_ATT_MLP = 0, NCF_ATT_LINEAR = 1, NCF_ATT_COS = 2 };
+int ncf_attn_forward(int mode,
+                     const float* dev_pc, int64_t ldpc, const float* dev_pr, int64_t ldpr, int A,
+                     const float* dev_w1, float b1,
+                     const int64_t* dev_rowptr, const int32_t* dev_col, const float* dev_val,
+                     int64_t B, int64_t I,
+                     const float* dev_feat, int64_t ldfeat, int Fdim,
+                     const float* dev_out_bias,
+                     float* dev_out_feat, int64_t ldout,
+                     float* dev_weights,
+                     ncf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NCF_ABI_H */

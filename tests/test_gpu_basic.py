@@ -1,0 +1,240 @@
+"""GPU parity tests (MI355X) for K1 gather, K2 MLP and the fused scoring kernel, through the C ABI.
+
+Bars: index gathers bit-exact (torch.equal); fp32 MLP within 1e-5 relative of the CPU oracle
+(|a-b| <= 1e-5 * |b| + 1e-5 * max|b|) — BASELINE.json north_star tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, onehot
+from oracle import ncf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def assert_close(a, ref, rtol=RTOL):
+    a = a.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert a.shape == ref.shape
+    tol = rtol * ref.abs() + rtol * ref.abs().max()
+    bad = (a - ref).abs() > tol
+    assert not bool(bad.any()), f"max abs err {(a - ref).abs().max().item():.3e}, ref scale {ref.abs().max().item():.3e}"
+
+
+@pytest.fixture(scope="module")
+def native(gpu):
+    from deeprecommendation_amd import native as n
+    n.load_library()
+    return n
+
+
+# ----------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("EA,EB", [(64, 64), (32, 32), (128, 128), (8, 8), (16, 48), (5, 3), (64, 0), (256, 256)])
+@pytest.mark.parametrize("B", [1, 63, 1000])
+def test_gather_concat_bit_exact(native, gpu, dtype, EA, EB, B):
+    g = torch.Generator().manual_seed(EA * 131 + EB + B)
+    ta = torch.randn(997, EA, generator=g).to(dtype).to(gpu)
+    tb = torch.randn(211, EB, generator=g).to(dtype).to(gpu) if EB else None
+    ia = torch.randint(0, 997, (B,), generator=g).to(gpu)
+    ib = torch.randint(0, 211, (B,), generator=g).to(gpu) if EB else None
+    out = native.gather_concat(ta, ia, tb, ib)
+    ref = torch.cat((ta[ia], tb[ib]), dim=1) if EB else ta[ia]
+    assert torch.equal(out, ref)
+
+
+def test_gather_edge_cases(native, gpu):
+    ta = torch.randn(50, 64, device=gpu)
+    tb = torch.randn(40, 64, device=gpu)
+    # empty batch
+    out = native.gather_concat(ta, torch.zeros(0, dtype=torch.long, device=gpu), tb, torch.zeros(0, dtype=torch.long, device=gpu))
+    assert out.shape == (0, 128)
+    # identity index (dense activations) + strided (non-contiguous rows) table view
+    big = torch.randn(50, 96, device=gpu)
+    view = big[:, :64]
+    out = native.gather_concat(view, None, tb[:50 - 10], None, B=40)
+    assert torch.equal(out, torch.cat((view[:40], tb[:40]), 1))
+    # maximum / minimum row ids, repeated ids
+    ia = torch.tensor([0, 49, 49, 0, 25], device=gpu)
+    ib = torch.tensor([39, 0, 39, 0, 1], device=gpu)
+    assert torch.equal(native.gather_concat(ta, ia, tb, ib), torch.cat((ta[ia], tb[ib]), 1))
+    # out-of-range ids never fault: zero row + sticky flag -> IndexError on check
+    bad = torch.tensor([0, 50, -1], device=gpu)
+    out = native.gather_concat(ta, bad, tb, torch.tensor([0, 1, 2], device=gpu))
+    assert torch.equal(out[0, :64], ta[0]) and float(out[1, :64].abs().sum()) == 0.0 and float(out[2, :64].abs().sum()) == 0.0
+    with pytest.raises(IndexError):
+        native.check_oob(gpu)
+    native.check_oob(gpu)  # flag was cleared
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_dot(native, gpu, dtype):
+    g = torch.Generator().manual_seed(3)
+    ta = torch.randn(300, 128, generator=g).to(dtype)
+    tb = torch.randn(200, 128, generator=g).to(dtype)
+    ia = torch.randint(0, 300, (777,), generator=g)
+    ib = torch.randint(0, 200, (777,), generator=g)
+    out = native.gather_dot(ta.to(gpu), ia.to(gpu), tb.to(gpu), ib.to(gpu))
+    ref = (ta[ia].double() * tb[ib].double()).sum(1, keepdim=True).float()
+    assert_close(out, ref, rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- K2 generic
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (128, 64, 32), (129, 65, 33), (300, 128, 2094), (1000, 256, 128),
+                                   (64, 1, 256), (513, 16, 20), (33, 9, 100)])
+def test_linear_generic(native, gpu, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / (K ** 0.5)
+    b = torch.randn(N, generator=g)
+    out = native.linear(x.to(gpu), w.to(gpu), b.to(gpu))
+    assert_close(out, torch.nn.functional.linear(x.double(), w.double(), b.double()).float())
+    out = native.linear(x.to(gpu), w.to(gpu), None)
+    assert_close(out, torch.nn.functional.linear(x.double(), w.double()).float())
+
+
+@pytest.mark.parametrize("dims", [[16, 16, 1], [24, 32, 16, 1], [128, 256, 128, 1], [20, 8], [100, 7, 5, 3, 2]])
+def test_mlp_generic(native, gpu, dims):
+    g = torch.Generator().manual_seed(sum(dims))
+    B = 257
+    x = torch.randn(B, dims[0], generator=g)
+    ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(len(dims) - 1)]
+    out = native.mlp_forward(x.to(gpu), [w.to(gpu) for w in ws], [b.to(gpu) for b in bs])
+    ref = O.mlp_forward(x.double(), [(w.double(), b.double()) for w, b in zip(ws, bs)]).float()
+    assert_close(out, ref)
+
+
+# ----------------------------------------------------------------------------- fused K1+K2
+FUSED_SHAPES = [(32, 32, [256, 128]), (32, 32, [256]), (32, 32, [128]), (32, 32, [128, 64]),
+                (64, 64, [256, 128]), (64, 64, [256]), (64, 64, [128]), (64, 64, [128, 64]),
+                (128, 128, [256, 128]), (128, 128, [256]), (128, 128, [128]), (96, 32, [256, 128]), (8, 120, [256])]
+
+
+@pytest.mark.parametrize("EA,EB,hidden", FUSED_SHAPES)
+@pytest.mark.parametrize("B", [1, 31, 32, 33, 1000])
+def test_score_fused_vs_oracle(native, gpu, EA, EB, hidden, B):
+    g = torch.Generator().manual_seed(EA + 7 * EB + len(hidden) + B)
+    dims = [EA + EB] + hidden + [1]
+    assert native.fused_supported(EA, EB, dims)
+    ta = torch.randn(500, EA, generator=g) * 0.5
+    tb = torch.randn(300, EB, generator=g) * 0.5
+    ia = torch.randint(0, 500, (B,), generator=g)
+    ib = torch.randint(0, 300, (B,), generator=g)
+    ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(len(dims) - 1)]
+    packed = native.PackedMLP([w.to(gpu) for w in ws], [b.to(gpu) for b in bs])
+    out = native.score_fused(ta.to(gpu), ia.to(gpu), tb.to(gpu), ib.to(gpu), packed)
+    x = torch.cat((ta[ia], tb[ib]), 1)
+    ref = O.mlp_forward(x.double(), [(w.double(), b.double()) for w, b in zip(ws, bs)]).float()
+    assert out.shape == (B, 1)
+    assert_close(out, ref)
+    # fused == unfused (K1 then K2) to the same tolerance
+    xg = native.gather_concat(ta.to(gpu), ia.to(gpu), tb.to(gpu), ib.to(gpu))
+    assert torch.equal(xg.cpu(), x)
+    out2 = native.mlp_forward(xg, [w.to(gpu) for w in ws], [b.to(gpu) for b in bs])
+    assert_close(out2, ref)
+
+
+def test_score_fused_asymmetric_weights_catch_layout_swaps(native, gpu):
+    """A = I style check with ASYMMETRIC integer data: exact in fp32, so any row/col or k-permutation mix-up
+    between the packed weights and the accumulator-as-operand chain shows as a hard mismatch."""
+    EA = EB = 32
+    dims = [64, 128, 64, 1]
+    B = 64
+    ta = torch.arange(40 * EA).reshape(40, EA).float() % 7 - 3
+    tb = torch.arange(30 * EB).reshape(30, EB).float() % 5 - 2
+    ws = [((torch.arange(dims[i + 1] * dims[i]).reshape(dims[i + 1], dims[i]) * 2654435761 % 11) - 5).float() for i in range(3)]
+    bs = [(torch.arange(dims[i + 1]) % 3 - 1).float() for i in range(3)]
+    ia = torch.arange(B) % 40
+    ib = (torch.arange(B) * 7) % 30
+    packed = native.PackedMLP([w.to(gpu) for w in ws], [b.to(gpu) for b in bs])
+    out = native.score_fused(ta.to(gpu), ia.to(gpu), tb.to(gpu), ib.to(gpu), packed)
+    ref = O.mlp_forward(torch.cat((ta[ia], tb[ib]), 1).double(), [(w.double(), b.double()) for w, b in zip(ws, bs)])
+    assert float(ref.abs().max()) < 2 ** 24  # integers: fp32 arithmetic is exact
+    assert torch.equal(out.cpu().double(), ref)
+
+
+# ----------------------------------------------------------------------------- models vs golden (reference outputs)
+def _model(cls, kw, state, gpu):
+    m = cls(**kw)
+    m.load_state_dict(state)
+    return m.eval().to(gpu)
+
+
+@pytest.mark.parametrize("name", ["g1_basic_onehot_small", "g1_basic_onehot_e32", "g1_basic_onehot_nodrop"])
+def test_basic_ncf_golden(gpu, name):
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    state, a, kw = load_golden(name)
+    m = _model(BasicNCF, kw, state, gpu)
+    ref = torch.from_numpy(a["out"])
+    with torch.no_grad():
+        out_idx = m(torch.as_tensor(a["user_pos"]).to(gpu), torch.as_tensor(a["item_pos"]).to(gpu))
+        out_dense = m(onehot(a["user_pos"], kw["user_dim"]).to(gpu), onehot(a["item_pos"], kw["item_dim"]).to(gpu))
+    assert_close(out_idx, ref)
+    assert_close(out_dense, ref)
+
+
+def test_basic_ncf_dense_profiles_golden(gpu):
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    state, a, kw = load_golden("g1_basic_dense_profiles")
+    m = _model(BasicNCF, kw, state, gpu)
+    with torch.no_grad():
+        out = m(torch.from_numpy(a["X_user"]).to(gpu), torch.from_numpy(a["X_item"]).to(gpu))
+    assert_close(out, torch.from_numpy(a["out"]))
+
+
+def test_mf_golden(gpu):
+    from deeprecommendation_amd.neural_collaborative_filtering.models.mf import MF
+    state, a, kw = load_golden("g2_mf_onehot")
+    m = _model(MF, kw, state, gpu)
+    ref = torch.from_numpy(a["out"])
+    with torch.no_grad():
+        out_idx = m(torch.as_tensor(a["user_pos"]).to(gpu), torch.as_tensor(a["item_pos"]).to(gpu))
+        out_dense = m(onehot(a["user_pos"], kw["user_dim"]).to(gpu), onehot(a["item_pos"], kw["item_dim"]).to(gpu))
+    assert_close(out_idx, ref)
+    assert_close(out_dense, ref)
+
+
+def test_cfg1_ml1m_golden(gpu):
+    """BASELINE configs[0] on the GPU: 20k pairs at 6040 x 3706, emb 32, MLP [256], batch 512."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    state, a, kw = load_golden("cfg1_basic_ml1m")
+    m = _model(BasicNCF, kw, state, gpu)
+    up = torch.as_tensor(a["user_pos"].astype(np.int64)).to(gpu)
+    ip = torch.as_tensor(a["item_pos"].astype(np.int64)).to(gpu)
+    with torch.no_grad():
+        out = torch.cat([m(up[s:s + 512], ip[s:s + 512]) for s in range(0, len(up), 512)])
+    assert_close(out, torch.from_numpy(a["out"]))
+
+
+def test_full_size_cfg2_properties(native, gpu):
+    """BASELINE configs[1] at full size (1M x 100k, emb 64, B = 65536): size-independent properties.
+    (a) fused == gather + generic MLP; (b) permuting the batch permutes the output bit-exactly;
+    (c) a subsample agrees with the CPU oracle."""
+    g = torch.Generator().manual_seed(1234)
+    U, I, E, B = 1_000_000, 100_000, 64, 65536
+    tu = (torch.randn(U, E, generator=g) * 0.05).to(gpu)
+    ti = (torch.randn(I, E, generator=g) * 0.05).to(gpu)
+    dims = [128, 256, 128, 1]
+    ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(3)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(3)]
+    packed = native.PackedMLP([w.to(gpu) for w in ws], [b.to(gpu) for b in bs])
+    iu = torch.randint(0, U, (B,), generator=g).to(gpu)
+    ii = torch.randint(0, I, (B,), generator=g).to(gpu)
+    iu[0], iu[1], ii[0], ii[1] = 0, U - 1, I - 1, 0  # extreme row ids
+    out = native.score_fused(tu, iu, ti, ii, packed)
+    x = native.gather_concat(tu, iu, ti, ii)
+    assert torch.equal(x, torch.cat((tu[iu], ti[ii]), 1))
+    out2 = native.mlp_forward(x, [w.to(gpu) for w in ws], [b.to(gpu) for b in bs])
+    assert_close(out, out2.cpu())
+    perm = torch.randperm(B, generator=g).to(gpu)
+    outp = native.score_fused(tu, iu[perm].contiguous(), ti, ii[perm].contiguous(), packed)
+    assert torch.equal(outp, out[perm])
+    sub = torch.arange(0, B, 97)
+    ref = O.mlp_forward(x[sub.to(gpu)].cpu().double(), [(w.double(), b.double()) for w, b in zip(ws, bs)]).float()
+    assert_close(out[sub.to(gpu)], ref)
+    native.check_oob(gpu)
