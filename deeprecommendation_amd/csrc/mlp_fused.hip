@@ -16,7 +16,31 @@
 // Bound: fp32 MFMA (157.3 TFLOP/s).  FLOP per pair = 2 * (K0*N1 + N1*N2 + N2)  (131 328 at 128-256-128-1).
 #include "ncf_common.h"
 
+#ifndef NCF_X_DEPTH
+#define NCF_X_DEPTH 4       // measured (interleaved A/B, cfg 2): 2 -> 72.4 us, 3 -> 70.0 us, 4 -> 69.5 us
+#endif
+#ifndef NCF_ABLATE_LOADS
+#define NCF_ABLATE_LOADS 0  // diagnostic: skip the in-loop weight / row loads (wrong results, pure MFMA stream timing)
+#endif
+#ifndef NCF_WG_WAVES
+#define NCF_WG_WAVES 4      // waves per workgroup (4 or 8)
+#endif
+#ifndef NCF_MIN_WAVES
+#define NCF_MIN_WAVES 2     // launch_bounds second argument: waves per SIMD the register budget must allow
+#endif
+#ifndef NCF_STAGGER
+#define NCF_STAGGER 0       // s_sleep units (64 clk) the second half of the workgroup's waves start late by
+#endif
+
+#ifndef NCF_STAMP
+#define NCF_STAMP 0         // diagnostic builds only (tools/ab_fused.py): per-wave s_memtime / s_memrealtime stamps
+#endif
+
 namespace ncf {
+
+#if NCF_STAMP
+static unsigned long long* g_dbg = nullptr;  // dev builds only; never present in the shipped library
+#endif
 
 struct FusedArgs {
     const float* tabA; int64_t rowsA; int64_t ldA;
@@ -27,18 +51,25 @@ struct FusedArgs {
     const float* Wp2; const float* b2;
     const float* wl; const float* bl;   // last (1-wide) layer: weights [Nlast], bias [1]
     float* out; int32_t* oob;
+#if NCF_STAMP
+    unsigned long long* dbg;
+#endif
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 template <int K0, int N1, int N2>
-__global__ __launch_bounds__(256, 2) void score_fused_f32_kernel(FusedArgs a) {
+__global__ __launch_bounds__(NCF_WG_WAVES * 64, NCF_MIN_WAVES) void score_fused_f32_kernel(FusedArgs a) {
     constexpr int NT1 = N1 / 32, Q1 = K0 / 8;
     constexpr int NT2 = N2 / 32, Q2 = N1 / 8;
     const int lane = threadIdx.x & 63;
     const int m = lane & 31, h = lane >> 5;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * NCF_WG_WAVES + (threadIdx.x >> 6);
     if (tile * 32 >= a.B) return;  // whole wave exits together
+#if NCF_STAMP
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (NCF_STAGGER > 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= NCF_WG_WAVES * 32) __builtin_amdgcn_s_sleep(NCF_STAGGER);
     const int64_t p = tile * 32 + m;
     const int64_t pc = p < a.B ? p : a.B - 1;
 
@@ -56,6 +87,18 @@ __global__ __launch_bounds__(256, 2) void score_fused_f32_kernel(FusedArgs a) {
     }
     if (!(okA & okB) && a.oob) *a.oob = 1;
     const float zA = okA ? 1.f : 0.f, zB = okB ? 1.f : 0.f;  // out-of-range rows read as zeros
+    // Touch every 128-byte line of this pair's two rows NOW (one dword each, lane half h takes lines h, h+2, ...):
+    // the HBM misses of all lines overlap each other and the bias / first-weight loads, instead of surfacing one
+    // by one at every 4th k-step of layer 1 (each step only prefetches one step ahead).
+#ifndef NCF_TOUCH
+#define NCF_TOUCH 0   // measured: touching all lines at kernel start is SLOWER (81 vs 75 us): 2048 waves issue the whole
+#endif                // batch's 34 MB of HBM misses at once and every wave's first weight wait queues behind them
+    if (NCF_TOUCH) {
+        float touch = 0.f;
+        for (int l = h; l * 32 < a.EA; l += 2) touch += rowA[l * 32 - 4 * h];
+        for (int l = h; l * 32 < K0 - a.EA; l += 2) touch += rowB[l * 32 - 4 * h];
+        asm volatile("" ::"v"(touch));
+    }
 
     // ---- layer 1: acc1 = b1 (broadcast over pairs) + W1 . X^T ----
     f32x16 acc1[NT1];
@@ -69,29 +112,43 @@ __global__ __launch_bounds__(256, 2) void score_fused_f32_kernel(FusedArgs a) {
         }
     {
         const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp1) + lane;  // + (q*NT1 + nt)*64
+        // XD = depth of the gathered-row prefetch ring: chunk q + XD - 1 is requested while step q computes.  The
+        // X load is issued AFTER the step's weight loads, so the in-order vmcnt wait for the next step's weights
+        // (older) never waits for it (younger): a row chunk that misses to HBM gets XD - 1 steps of cover.
+        constexpr int XD = NCF_X_DEPTH;
         f32x4 w[2][NT1];
-        f32x4 x[2];
+        f32x4 x[XD];
+        auto xsrc = [&](int q) { return q < qa ? rowA + 8 * q : rowB + 8 * (q - qa); };  // wave-uniform: EA % 8 == 0
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt) w[0][nt] = wp[nt * 64];
-        x[0] = ldg4(0 < qa ? rowA : rowB);
+#pragma unroll
+        for (int t = 0; t < XD - 1; ++t)
+            if (t < Q1) x[t] = ldg4(xsrc(t));
 #pragma unroll
         for (int q = 0; q < Q1; ++q) {
+            // One scheduling region per k-step.  MFMAs run nt-major (4 dependent MFMAs per accumulator: the 64-cycle
+            // dependent latency of 32x32x2 equals its issue interval, so that costs nothing) and the NEXT step's
+            // weight load for tile nt is issued right behind tile nt's MFMAs, in the order the next step consumes
+            // them: every load is issued in the shadow of a running MFMA and gets a full step of cover, and the
+            // compiler's counted vmcnt waits only for the tile it is about to use.
             const int cur = q & 1, nxt = cur ^ 1;
-            if (q + 1 < Q1) {
+            const f32x4 xb = x[q % XD] * (q < qa ? zA : zB);  // zero an out-of-range row at USE time
 #pragma unroll
-                for (int nt = 0; nt < NT1; ++nt) w[nxt][nt] = wp[((q + 1) * NT1 + nt) * 64];
-                const bool fromA = q + 1 < qa;  // wave-uniform: EA % 8 == 0
-                x[nxt] = ldg4(fromA ? rowA + 8 * (q + 1) : rowB + 8 * (q + 1 - qa));
-            }
-            // pin the prefetch ABOVE this step's MFMAs: without it hipcc sinks each load to just before its use
-            // (load -> vmcnt(0) -> 4 MFMAs ...), exposing the L2 latency 8 times per step.
-            __builtin_amdgcn_sched_barrier(0);
-            const f32x4 xb = x[cur] * (q < qa ? zA : zB);  // zero an out-of-range row at USE time (keeps the load un-waited)
-#pragma unroll
-            for (int nt = 0; nt < NT1; ++nt)
+            for (int nt = 0; nt < NT1; ++nt) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], xb[j], acc1[nt], 0, 0, 0);
+                if (q + 1 < Q1) w[nxt][nt] = NCF_ABLATE_LOADS ? w[cur][nt] : wp[((q + 1) * NT1 + nt) * 64];
+            }
+            if (q + XD - 1 < Q1) x[(q + XD - 1) % XD] = NCF_ABLATE_LOADS ? x[q % XD] : ldg4(xsrc(q + XD - 1));
+            if (!NCF_ABLATE_LOADS) {
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -116,17 +173,22 @@ __global__ __launch_bounds__(256, 2) void score_fused_f32_kernel(FusedArgs a) {
         for (int q = 0; q < Q2; ++q) {  // q = 4*kb + g : k-block kb of H1 (= tile kb of acc1), group g
             const int cur = q & 1, nxt = cur ^ 1;
             const int kb = q >> 2, g = q & 3;
-            if (q + 1 < Q2) {
+            f32x4 hv;
 #pragma unroll
-                for (int nt = 0; nt < NT2; ++nt) w[nxt][nt] = wp[((q + 1) * NT2 + nt) * 64];
+            for (int j = 0; j < 4; ++j) hv[j] = fmaxf(acc1[kb][4 * g + j], 0.f);  // ReLU (util.py:15)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], hv[j], acc2[nt], 0, 0, 0);
+                if (q + 1 < Q2) w[nxt][nt] = NCF_ABLATE_LOADS ? w[cur][nt] : wp[((q + 1) * NT2 + nt) * 64];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (!NCF_ABLATE_LOADS) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float hv = fmaxf(acc1[kb][4 * g + j], 0.f);  // ReLU (util.py:15)
-#pragma unroll
-                for (int nt = 0; nt < NT2; ++nt)
-                    acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], hv, acc2[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT2; ++nt) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -151,6 +213,15 @@ __global__ __launch_bounds__(256, 2) void score_fused_f32_kernel(FusedArgs a) {
     }
     partial += __shfl_xor(partial, 32);  // the two lane halves hold complementary neuron rows
     if (h == 0 && p < a.B) a.out[p] = partial + a.bl[0];
+#if NCF_STAMP
+    if (a.dbg && lane == 0) {
+        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        a.dbg[tile * 4 + 0] = st_t1 - st_t0;   // shader cycles
+        a.dbg[tile * 4 + 1] = st_r1 - st_r0;   // 100 MHz ticks
+        a.dbg[tile * 4 + 2] = st_r0;
+        a.dbg[tile * 4 + 3] = st_r1;
+    }
+#endif
 }
 
 // Pack W [N][K] row-major into Wp[q][nt][lane][4].
@@ -198,8 +269,8 @@ typedef void (*fused_fn)(FusedArgs);
 template <int K0, int N1, int N2>
 static void launch_inst(const FusedArgs& a, hipStream_t s) {
     const int64_t tiles = (a.B + 31) / 32;
-    const unsigned blocks = (unsigned)((tiles + 3) / 4);
-    hipLaunchKernelGGL((score_fused_f32_kernel<K0, N1, N2>), dim3(blocks), dim3(256), 0, s, a);
+    const unsigned blocks = (unsigned)((tiles + NCF_WG_WAVES - 1) / NCF_WG_WAVES);
+    hipLaunchKernelGGL((score_fused_f32_kernel<K0, N1, N2>), dim3(blocks), dim3(NCF_WG_WAVES * 64), 0, s, a);
 }
 
 #define NCF_FUSED_INSTANCES(X) \
@@ -285,6 +356,13 @@ extern "C" int ncf_score_fused(int dtype, const void* tabA, int64_t rowsA, int64
     a.Wp2 = n_layers == 3 ? P + L.wp2 : nullptr; a.b2 = n_layers == 3 ? P + L.b2 : nullptr;
     a.wl = P + L.wl; a.bl = P + L.bl;
     a.out = out; a.oob = oob;
+#if NCF_STAMP
+    a.dbg = g_dbg;
+#endif
     fused_dispatch(dims[0], dims[1], n_layers == 3 ? dims[2] : 0, &a, (hipStream_t)stream);
     return check_launch("ncf_score_fused");
 }
+
+#if NCF_STAMP
+extern "C" void ncf_dev_set_debug_buffer(void* p) { ncf::g_dbg = (unsigned long long*)p; }
+#endif

@@ -1,0 +1,82 @@
+"""Condense gpurun_out/prof_<tag>/ (tools/profile.sh output) into profiles/<tag>_*.csv + profiles/<tag>_summary.md.
+
+Only this repo's kernels (ncf::*) are kept — torch's initialisation kernels have kilobyte-long names.
+PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE tallies 128-B read requests at 64 B, so the read side is DOUBLED before comparing with a byte count.
+"""
+import csv
+import os
+import re
+import sys
+from collections import defaultdict
+
+csv.field_size_limit(1 << 30)
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"(ncf::[A-Za-z0-9_]+(<[^>]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
+def main(tag):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(root, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    lines = [f"# rocprofv3 summary — {tag}", "",
+             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline`",
+             "(plus one `--pmc` pass per counter group; see tools/profile.sh).  Only `ncf::` kernels listed.", ""]
+    stats = os.path.join(src, "trace", "trace_kernel_stats.csv")
+    rows = []
+    if os.path.exists(stats):
+        with open(stats) as f:
+            for r in csv.DictReader(f):
+                if "ncf::" in r["Name"]:
+                    rows.append(r)
+        with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"], r["StdDev"]])
+        lines += ["## kernel stats (--kernel-trace --stats)", "",
+                  "| kernel | calls | avg µs | min µs | max µs | % of GPU time |", "|---|---|---|---|---|---|"]
+        for r in rows:
+            lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | "
+                         f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")
+        lines.append("")
+    agg = defaultdict(lambda: defaultdict(list))
+    for sub in sorted(os.listdir(src)) if os.path.isdir(src) else []:
+        p = os.path.join(src, sub, "pmc_counter_collection.csv")
+        if not os.path.exists(p):
+            continue
+        with open(p) as f:
+            for r in csv.DictReader(f):
+                if "ncf::" not in r["Kernel_Name"]:
+                    continue
+                k = short(r["Kernel_Name"])
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if agg:
+        lines += ["## PMC counters (mean per launch)", "", "| kernel | counter | mean per launch | note |", "|---|---|---|---|"]
+        with open(os.path.join(dst, f"{tag}_pmc.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "counter", "launches", "mean_per_launch"])
+            for k, cs in sorted(agg.items()):
+                for c, vals in sorted(cs.items()):
+                    mean = sum(vals) / len(vals)
+                    w.writerow([k, c, len(vals), f"{mean:.6g}"])
+                    note = ""
+                    if c == "FETCH_SIZE":
+                        note = f"= {mean*1024*2/1e6:.2f} MB read per launch after the gfx950 x2 correction ({mean*1024/1e6:.2f} MB raw)"
+                    elif c == "WRITE_SIZE":
+                        note = f"= {mean*1024/1e6:.2f} MB written per launch"
+                    lines.append(f"| `{k}` | {c} | {mean:.6g} | {note} |")
+        lines.append("")
+    with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
