@@ -176,9 +176,40 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ pc,
     (void)nnz;
 }
 
+// out[r,:] = x[r,:] / max(||x[r,:]||_2, 1e-12)   (torch.nn.functional.normalize(p=2, dim=1), attention_ncf.py:167-168)
+__global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t R, int E,
+                                                                float* __restrict__ out, int64_t ldo) {
+    const int sub = threadIdx.x & 15;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int64_t Rpad = (R + 3) & ~int64_t(3);
+    for (int64_t r = grp; r < Rpad; r += ngrp) {
+        float ss = 0.f;
+        if (r < R)
+            for (int e = sub; e < E; e += 16) ss = fmaf(x[r * ldx + e], x[r * ldx + e], ss);
+        ss += __shfl_xor(ss, 8);
+        ss += __shfl_xor(ss, 4);
+        ss += __shfl_xor(ss, 2);
+        ss += __shfl_xor(ss, 1);
+        if (r < R) {
+            const float d = fmaxf(sqrtf(ss), 1e-12f);
+            for (int e = sub; e < E; e += 16) out[r * ldo + e] = x[r * ldx + e] / d;
+        }
+    }
+}
+
 }  // namespace ncf
 
 using namespace ncf;
+
+extern "C" int ncf_l2_normalize_rows(const float* x, int64_t ldx, int64_t R, int E, float* out, int64_t ldo, ncf_stream_t stream) {
+    if (R == 0) return NCF_OK;
+    if (R < 0 || E <= 0 || !x || !out || ldx < E || ldo < E) return fail(NCF_EINVAL, "ncf_l2_normalize_rows: bad argument");
+    int64_t blocks = (R + 15) / 16;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, R, E, out, ldo);
+    return check_launch("ncf_l2_normalize_rows");
+}
 
 extern "C" int ncf_attn_forward(int mode, const float* pc, int64_t ldpc, const float* pr, int64_t ldpr, int A,
                                 const float* w1, float b1, const int64_t* rowptr, const int32_t* col, const float* val,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "ncf_scale_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, ctypes.c_float, _c_p, _c_i64, _c_p]),
     "ncf_attn_forward": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
                                   _c_i64, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "ncf_l2_normalize_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p]),
 }
 
 _lib = None
@@ -327,3 +328,12 @@ def attn_forward(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[tor
     _check(lib.ncf_attn_forward(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), float(b1), _ptr(rowptr), _ptr(col), _ptr(val),
                                 B, I, _ptr(feat), ldf, Fdim, _ptr(out_bias), _ptr(out), out.stride(0), _ptr(wts), _stream(pc)))
     return out, wts[:col.numel()]
+
+
+def l2_normalize_rows(x: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    _dev(x, "x")
+    R, E, ld = _rows2d(x, "x")
+    out = torch.empty((R, E), dtype=torch.float32, device=x.device)
+    _check(lib.ncf_l2_normalize_rows(_ptr(x), ld, R, E, _ptr(out), out.stride(0), _stream(x)))
+    return out

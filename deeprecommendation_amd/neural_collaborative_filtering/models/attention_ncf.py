@@ -1,0 +1,176 @@
+"""AttentionNCF — drop-in for reference models/attention_ncf.py:64-224 (same kwargs, state_dict keys, forward).
+
+HIP scoring path (eval / no-grad), all arithmetic in libncf_hip.so:
+  1. ItemEmbeddings on candidates and rated items                         (attention_ncf.py:150-151)  ncf_mlp_forward
+  2. AttentionNet's first Linear is split at the concat boundary of :176,  W0 = [Wc | Wr]:
+        pc = cand_emb @ Wc^T + b0   (B, A),   pr = rated_emb @ Wr^T   (I, A)
+     so the score of a pair is  b1 + w1 . relu(pc[b] + pr[i])  — no (B·nnz, 2·IE) pair matrix, no per-pair GEMM.
+  3. scores -> masked softmax -> x ratings -> weighted sum              (:182-213)                  ncf_attn_forward
+     over the CSR of `user_matrix != 0` (:158).  The weighted sum uses the linearity of UserEmbeddings (:216):
+        UserEmbeddings(sum_i a_i f_i) = sum_i a_i (f_i @ Wu^T) + bu
+     so the kernel aggregates the projected rows P = rated_items @ Wu^T (I, UE) instead of F-wide feature rows.
+  4. cat(candidate_emb, user_emb) -> MLP                                 (:219-222)                  ncf_score_fused
+Both reformulations change only the fp32 summation order (tests hold them to 1e-5 relative of the reference).
+A training step keeps to differentiable torch ops with the reference's train-only message dropout and target mask.
+"""
+import sys
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import native
+from ..util import build_MLP_layers, require_gpu, use_native
+from .base import NCF
+from .basic_ncf import _ScoringMixin
+
+
+class SparseRatings:
+    """CSR form of the (B, I) ``user_matrix``: row b owns entries [rowptr[b], rowptr[b+1]) with ``col`` = position in
+    the rated-item list and ``val`` = the non-zero normalised rating.  Providers can emit this directly instead of
+    the dense matrix (which is 2·B·I floats of mostly zeros)."""
+
+    def __init__(self, rowptr, col, val, num_items):
+        self.rowptr, self.col, self.val, self.num_items = rowptr, col, val, int(num_items)
+
+    @staticmethod
+    def from_dense(user_matrix: torch.Tensor) -> "SparseRatings":
+        mask = user_matrix != 0  # attention_ncf.py:158 — an entry that is exactly 0 counts as unrated
+        rowptr = torch.zeros(user_matrix.shape[0] + 1, dtype=torch.int64, device=user_matrix.device)
+        rowptr[1:] = torch.cumsum(mask.sum(dim=1), 0)
+        nz = mask.nonzero()  # row-major: sorted by row, then by column
+        return SparseRatings(rowptr, nz[:, 1].to(torch.int32).contiguous(), user_matrix[mask].float().contiguous(),
+                             user_matrix.shape[1])
+
+    def to_dense(self, values: torch.Tensor) -> torch.Tensor:
+        B = self.rowptr.numel() - 1
+        rows = torch.repeat_interleave(torch.arange(B, device=values.device), self.rowptr[1:] - self.rowptr[:-1])
+        out = torch.zeros((B, self.num_items), dtype=values.dtype, device=values.device)
+        out[rows, self.col.long()] = values
+        return out
+
+
+class AttentionNCF(_ScoringMixin, NCF):
+    compatible_datasets = ("DynamicPointwiseDataset", "DynamicRankingDataset")
+
+    def __init__(self, item_dim, item_emb=128, user_emb=128, att_dense=None, mlp_dense_layers=None,
+                 use_cos_sim_instead=False, dropout_rate=0.2, message_dropout=None):
+        super().__init__()
+        if mlp_dense_layers is None:
+            mlp_dense_layers = [256, 128]
+        self.kwargs = {'item_dim': item_dim, 'item_emb': item_emb, 'user_emb': user_emb, 'att_dense': att_dense,
+                       'mlp_dense_layers': mlp_dense_layers, 'dropout_rate': dropout_rate,
+                       'use_cos_sim_instead': use_cos_sim_instead, 'message_dropout': message_dropout}
+        self.use_cos_sim_instead = use_cos_sim_instead
+        self.message_dropout = message_dropout
+        self.ItemEmbeddings = nn.Sequential(nn.Linear(item_dim, item_emb))
+        self.UserEmbeddings = nn.Sequential(nn.Linear(item_dim, user_emb))
+        if not use_cos_sim_instead:
+            if att_dense is not None:
+                self.att_dense = att_dense
+                self.AttentionNet = nn.Sequential(nn.Linear(2 * item_emb, att_dense), nn.ReLU(), nn.Dropout(dropout_rate),
+                                                  nn.Linear(att_dense, 1))
+            else:
+                self.att_dense = 0
+                self.AttentionNet = nn.Sequential(nn.Linear(2 * item_emb, 1))
+        self.MLP = build_MLP_layers(item_emb + user_emb, mlp_dense_layers, dropout_rate=dropout_rate)
+
+    def get_model_parameters(self) -> dict:
+        return self.kwargs
+
+    def important_hypeparams(self) -> str:
+        return '_cosine' if self.use_cos_sim_instead else f'_attNet{self.att_dense}'
+
+    # ------------------------------------------------------------------------------------------ HIP scoring
+    def _att_split(self):
+        """Contiguous halves of AttentionNet.0 split at the cat(candidate, rated) boundary (:176)."""
+        cache = self._refresh()
+        if "att_split" not in cache:
+            l0 = self.AttentionNet[0]
+            IE = self.ItemEmbeddings[0].out_features
+            w = l0.weight.detach()
+            cache["att_split"] = (w[:, :IE].contiguous(), w[:, IE:].contiguous(), l0.bias.detach().contiguous())
+        return cache["att_split"]
+
+    def precompute_catalog(self, rated_items: torch.Tensor):
+        """Everything that depends only on the rated-item list: its embeddings, the rated half of the attention
+        projection and the UserEmbeddings projection of the raw features.  Cached for the last list seen (serving
+        scores one user against the whole catalogue, reference webapp/backend.py:78-121)."""
+        cache = self._refresh()
+        key = (rated_items.data_ptr(), tuple(rated_items.shape), rated_items._version)
+        hit = cache.get("catalog")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        x = rated_items.float().contiguous()
+        li, lu = self.ItemEmbeddings[0], self.UserEmbeddings[0]
+        rated_emb = native.linear(x, li.weight.detach(), li.bias.detach())
+        if self.use_cos_sim_instead:
+            pr = native.l2_normalize_rows(rated_emb)
+        else:
+            _, wr, _ = self._att_split()
+            pr = native.linear(rated_emb, wr, None)
+        proj = native.linear(x, lu.weight.detach(), None)  # P = rated_items @ Wu^T ; bias added once per user row
+        val = (rated_emb, pr, proj)
+        cache["catalog"] = (key, val, rated_items)
+        return val
+
+    def forward(self, candidate_items, rated_items, user_matrix, return_attention_weights=False):
+        if not use_native(self):
+            return self._forward_train(candidate_items, rated_items, user_matrix, return_attention_weights)
+        require_gpu(candidate_items, rated_items)
+        li, lu = self.ItemEmbeddings[0], self.UserEmbeddings[0]
+        cand_emb = native.linear(candidate_items.float().contiguous(), li.weight.detach(), li.bias.detach())
+        rated_emb, pr, proj = self.precompute_catalog(rated_items)
+        ratings = user_matrix if isinstance(user_matrix, SparseRatings) else SparseRatings.from_dense(user_matrix)
+        if self.use_cos_sim_instead:
+            mode, pc, w1, b1 = native.ATT_COS, native.l2_normalize_rows(cand_emb), None, 0.0
+        else:
+            wc, _, b0 = self._att_split()
+            pc = native.linear(cand_emb, wc, b0)
+            if self.att_dense:
+                l1 = self.AttentionNet[-1]
+                cache = self._refresh()
+                if "att_out" not in cache:
+                    cache["att_out"] = (l1.weight.detach().reshape(-1).contiguous(), float(l1.bias.detach().item()))
+                w1, b1 = cache["att_out"]
+                mode = native.ATT_MLP
+            else:
+                mode, w1, b1 = native.ATT_LINEAR, None, 0.0
+        user_emb, wts = native.attn_forward(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val, proj,
+                                            out_bias=lu.bias.detach())
+        out = self._score(cand_emb, None, user_emb, None)  # cat(candidate_emb, user_emb): :219
+        if return_attention_weights:
+            return out, ratings.to_dense(wts)
+        return out
+
+    # ------------------------------------------------------------------------------------------ torch training path
+    def _forward_train(self, candidate_items, rated_items, user_matrix, return_attention_weights):
+        if isinstance(user_matrix, SparseRatings):
+            user_matrix = user_matrix.to_dense(user_matrix.val)
+        B, I = candidate_items.shape[0], rated_items.shape[0]
+        cand_emb = self.ItemEmbeddings(candidate_items)
+        rated_emb = self.ItemEmbeddings(rated_items)
+        valid = user_matrix != 0
+        pairs = valid.nonzero()
+        c, r = cand_emb[pairs[:, 0]], rated_emb[pairs[:, 1]]
+        if self.use_cos_sim_instead:
+            att = (F.normalize(c, p=2, dim=1) * F.normalize(r, p=2, dim=1)).sum(dim=1)
+        else:
+            att = self.AttentionNet(torch.cat((c, r), dim=1)).view(-1)
+        if self.training and self.message_dropout is not None:
+            att = F.dropout(att, p=self.message_dropout, training=True)
+            att = torch.where(att == 0, torch.full_like(att, -float('inf')), att)
+        scores = torch.full((B, I), -float('inf'), dtype=torch.float32, device=att.device)
+        scores[valid] = att
+        if self.training:
+            # the candidate itself must not attend to itself while fitting its rating (:195-205)
+            try:
+                same = torch.isclose(cand_emb.unsqueeze(1), rated_emb.unsqueeze(0), atol=1e-5).all(dim=2)
+                scores = scores.masked_fill(same, -float('inf'))
+            except Exception:  # the reference only warns here
+                print("Warning: Could not calculate training mask. Ignoring masking this time.", file=sys.stderr)
+        scores = F.softmax(scores, dim=1).nan_to_num(nan=0.0, posinf=0.0, neginf=0.0)
+        user_feat = torch.matmul(scores * user_matrix, rated_items)
+        user_emb = self.UserEmbeddings(user_feat)
+        out = self.MLP(torch.cat((cand_emb, user_emb), dim=1))
+        return (out, scores.detach()) if return_attention_weights else out

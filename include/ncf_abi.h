@@ -188,6 +188,11 @@ int ncf_attn_forward(int mode,
                      float* dev_weights,
                      ncf_stream_t stream);
 
+/* out[r, :] = x[r, :] / max(||x[r, :]||_2, 1e-12) — torch.nn.functional.normalize(p=2, dim=1) of the cosine
+ * variant, models/attention_ncf.py:167-168. */
+int ncf_l2_normalize_rows(const float* dev_x, int64_t ldx, int64_t R, int E, float* dev_out, int64_t ldout,
+                          ncf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
