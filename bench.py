@@ -65,11 +65,24 @@ def make_batches(device, rank):
             for _ in range(N_BATCHES)]
 
 
+def host_cores():
+    """CPU share of this process: the cgroup quota when there is one (the GPU box gives 16 of 256 cores), else the
+    affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(model, seconds=12.0):
     """CPU oracle (table formulation of the reference forward, PyTorch CPU fp32) on the host cores: same tables,
     same batch size; bounded to ~`seconds` of CPU work."""
     from oracle import ncf_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     tu = O.embedding_table(state["user_embeddings.0.weight"], state["user_embeddings.0.bias"])
@@ -102,7 +115,12 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+                    help="cfg2 = BASELINE headline (default); cfg3 / cfg4 = the other single-GPU configs (bench_extra.py)")
     args = ap.parse_args()
+    if args.workload != "cfg2":
+        import bench_extra
+        return bench_extra.main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
