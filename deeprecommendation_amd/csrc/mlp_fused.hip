@@ -299,18 +299,25 @@ static bool fused_shape_ok(int dtype, int EA, int EB, int n_layers, const int* d
 using namespace ncf;
 
 extern "C" int ncf_score_fused_supported(int dtype, int EA, int EB, int n_layers, const int* dims) {
+    if (dtype == NCF_BF16) return bf16_shape_ok(EA, EB, n_layers, dims) ? 1 : 0;
     return fused_shape_ok(dtype, EA, EB, n_layers, dims) ? 1 : 0;
 }
 
 extern "C" size_t ncf_mlp_packed_bytes(int dtype, int n_layers, const int* dims) {
+    if (dtype == NCF_BF16) return bf16_packed_bytes(n_layers, dims);
     if (dtype != NCF_F32 || !dims || (n_layers != 2 && n_layers != 3)) return 0;
     return blob_layout(dims, n_layers).total * sizeof(float);
 }
 
 extern "C" int ncf_mlp_pack(int dtype, int n_layers, const int* dims, const void* const* W, const void* const* b,
                             void* packed, size_t packed_bytes, ncf_stream_t stream) {
-    if (dtype != NCF_F32) return fail(NCF_EUNSUPPORTED, "ncf_mlp_pack: fp32 only");
+    if (dtype != NCF_F32 && dtype != NCF_BF16) return fail(NCF_EINVAL, "ncf_mlp_pack: bad dtype %d", dtype);
     if (!dims || !W || !packed || (n_layers != 2 && n_layers != 3)) return fail(NCF_EINVAL, "ncf_mlp_pack: bad argument");
+    if (dtype == NCF_BF16) {
+        for (int i = 0; i < n_layers; ++i)
+            if (!W[i]) return fail(NCF_EINVAL, "ncf_mlp_pack: W[%d] is null", i);
+        return bf16_pack(n_layers, dims, W, b, packed, packed_bytes, (hipStream_t)stream);
+    }
     if (dims[n_layers] != 1) return fail(NCF_EUNSUPPORTED, "ncf_mlp_pack: last layer must be 1 wide");
     for (int i = 0; i < n_layers; ++i) {
         if (!W[i]) return fail(NCF_EINVAL, "ncf_mlp_pack: W[%d] is null", i);
@@ -339,6 +346,13 @@ extern "C" int ncf_score_fused(int dtype, const void* tabA, int64_t rowsA, int64
                                int64_t ldB, const int64_t* idxA, const int64_t* idxB, int64_t B, int EA, int EB,
                                int n_layers, const int* dims, const void* packed, float* out, int32_t* oob,
                                ncf_stream_t stream) {
+    if (dtype == NCF_BF16) {
+        if (!bf16_shape_ok(EA, EB, n_layers, dims))
+            return fail(NCF_EUNSUPPORTED, "ncf_score_fused: no bf16 kernel for EA=%d EB=%d layers=%d", EA, EB, n_layers);
+        if (B == 0) return NCF_OK;
+        if (B < 0 || !tabA || (EB > 0 && !tabB) || !packed || !out) return fail(NCF_EINVAL, "ncf_score_fused: bad argument");
+        return bf16_score(tabA, rowsA, ldA, tabB, rowsB, ldB, idxA, idxB, B, EA, EB, n_layers, dims, packed, out, oob, (hipStream_t)stream);
+    }
     if (!fused_shape_ok(dtype, EA, EB, n_layers, dims))
         return fail(NCF_EUNSUPPORTED, "ncf_score_fused: no specialised kernel for dtype=%d EA=%d EB=%d layers=%d", dtype, EA, EB, n_layers);
     if (B == 0) return NCF_OK;

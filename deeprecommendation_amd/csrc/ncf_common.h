@@ -39,4 +39,13 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short v) { return __uint_a
 // row = (r & 3) + 8 * (r >> 2) + 4 * h   (MI355X C/D layout, dtype independent).
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// bf16 fused path (mlp_bf16.hip), reached through the dtype argument of the ncf_mlp_pack / ncf_score_fused entries
+bool bf16_shape_ok(int EA, int EB, int n_layers, const int* dims);
+size_t bf16_packed_bytes(int n_layers, const int* dims);
+int bf16_pack(int n_layers, const int* dims, const void* const* W, const void* const* b, void* packed, size_t packed_bytes,
+              hipStream_t s);
+int bf16_score(const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, int64_t rowsB, int64_t ldB, const int64_t* idxA,
+               const int64_t* idxB, int64_t B, int EA, int EB, int n_layers, const int* dims, const void* packed, float* out,
+               int32_t* oob, hipStream_t s);
+
 }  // namespace ncf

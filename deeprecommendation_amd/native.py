@@ -218,13 +218,17 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 class PackedMLP:
     """Weights of an MLP ending in a 1-wide layer, pre-packed for ncf_score_fused (built once per model)."""
 
-    def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+    def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], dtype=torch.float32):
+        """``dtype`` selects the kernel family: float32 (exact fp32 MFMA chain) or bfloat16 (weights rounded to bf16
+        at pack time, bf16 tables, fp32 accumulate).  Sources are always fp32 [out][in] tensors."""
         lib = load_library()
         self.dims = [int(weights[0].shape[1])] + [int(w.shape[0]) for w in weights]
         self.n_layers = len(weights)
         self.device = weights[0].device
+        self.dtype = dtype
+        self.dt = NCF_F32 if dtype == torch.float32 else NCF_BF16
         d = _dims_array(self.dims)
-        nbytes = lib.ncf_mlp_packed_bytes(NCF_F32, self.n_layers, d)
+        nbytes = lib.ncf_mlp_packed_bytes(self.dt, self.n_layers, d)
         if nbytes == 0:
             raise NativeError(NCF_EUNSUPPORTED, "MLP shape cannot be packed for the fused kernel")
         ws = [w.detach().to(torch.float32).contiguous() for w in weights]
@@ -232,15 +236,16 @@ class PackedMLP:
         for w in ws:
             _dev(w, "weight")
         self.blob = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        _check(lib.ncf_mlp_pack(NCF_F32, self.n_layers, d, _ptr_array(ws), _ptr_array(bs), _ptr(self.blob), nbytes,
+        _check(lib.ncf_mlp_pack(self.dt, self.n_layers, d, _ptr_array(ws), _ptr_array(bs), _ptr(self.blob), nbytes,
                                 _stream(ws[0])))
 
     def supports(self, EA: int, EB: int) -> bool:
-        return bool(load_library().ncf_score_fused_supported(NCF_F32, EA, EB, self.n_layers, _dims_array(self.dims)))
+        return bool(load_library().ncf_score_fused_supported(self.dt, EA, EB, self.n_layers, _dims_array(self.dims)))
 
 
-def fused_supported(EA: int, EB: int, dims: Sequence[int]) -> bool:
-    return bool(load_library().ncf_score_fused_supported(NCF_F32, EA, EB, len(dims) - 1, _dims_array(dims)))
+def fused_supported(EA: int, EB: int, dims: Sequence[int], dtype=torch.float32) -> bool:
+    dt = NCF_F32 if dtype == torch.float32 else NCF_BF16
+    return bool(load_library().ncf_score_fused_supported(dt, EA, EB, len(dims) - 1, _dims_array(dims)))
 
 
 def score_fused(tabA: torch.Tensor, idxA, tabB: Optional[torch.Tensor], idxB, packed: PackedMLP,
@@ -257,6 +262,8 @@ def score_fused(tabA: torch.Tensor, idxA, tabB: Optional[torch.Tensor], idxB, pa
         B = idxA.numel() if idxA is not None else (idxB.numel() if idxB is not None else rowsA)
     if out is None:
         out = torch.empty((B, 1), dtype=torch.float32, device=tabA.device)
+    if tabA.dtype != packed.dtype:
+        raise TypeError(f"tables are {tabA.dtype} but the MLP was packed for {packed.dtype}")
     _check(lib.ncf_score_fused(_dt(tabA), _ptr(tabA), rowsA, ldA, _ptr(tabB), rowsB, ldB, _ptr(idxA), _ptr(idxB), B, EA, EB,
                                packed.n_layers, _dims_array(packed.dims), _ptr(packed.blob), _ptr(out),
                                _ptr(_oob_flag(tabA.device)), _stream(tabA)))

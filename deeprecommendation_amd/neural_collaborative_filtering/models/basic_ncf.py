@@ -18,6 +18,17 @@ from .base import NCF
 class _ScoringMixin:
     """Derived inference tensors shared by BasicNCF / MF / GraphNCF: embedding tables and packed MLP weights."""
 
+    scoring_dtype = torch.float32
+
+    def set_scoring_dtype(self, dtype):
+        """float32 (default; 1e-5 parity with the reference) or bfloat16 (BASELINE config 5: bf16 tables and MLP
+        weights, fp32 accumulate and output).  Only the int64-position table path has a bf16 kernel."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("scoring dtype must be float32 or bfloat16")
+        self.scoring_dtype = dtype
+        self._native_ver = None
+        return self
+
     def _refresh(self):
         ver = params_version(self)
         if getattr(self, "_native_ver", None) != ver:
@@ -30,7 +41,7 @@ class _ScoringMixin:
         if name not in cache:
             with torch.no_grad():
                 # row i = W[:, i] + b : exactly what Linear(onehot(i)) computes (one fp32 rounding)
-                cache[name] = (lin.weight.detach().t().contiguous() + lin.bias.detach()).contiguous()
+                cache[name] = (lin.weight.detach().t().contiguous() + lin.bias.detach()).to(self.scoring_dtype).contiguous()
         return cache[name]
 
     def _packed_mlp(self, name: str = "MLP"):
@@ -39,7 +50,7 @@ class _ScoringMixin:
         if key not in cache:
             lins = mlp_linears(getattr(self, name))
             try:
-                cache[key] = native.PackedMLP([l.weight for l in lins], [l.bias for l in lins])
+                cache[key] = native.PackedMLP([l.weight for l in lins], [l.bias for l in lins], dtype=self.scoring_dtype)
             except native.NativeError as e:
                 if e.code != native.NCF_EUNSUPPORTED:
                     raise
@@ -51,8 +62,10 @@ class _ScoringMixin:
         packed = self._packed_mlp(mlp_name)
         EA = tabA.shape[1]
         EB = 0 if tabB is None else tabB.shape[1]
-        if packed is not None and packed.supports(EA, EB):
+        if packed is not None and tabA.dtype == packed.dtype and packed.supports(EA, EB):
             return native.score_fused(tabA, idxA, tabB, idxB, packed)
+        if tabA.dtype != torch.float32:
+            raise native.NativeError(native.NCF_EUNSUPPORTED, f"no bf16 kernel for EA={EA} EB={EB} MLP {getattr(packed, 'dims', None)}")
         x = native.gather_concat(tabA, idxA, tabB, idxB)
         lins = mlp_linears(getattr(self, mlp_name))
         return native.mlp_forward(x, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])

@@ -93,6 +93,27 @@ def basic_ncf_forward_indexed(state: State, user_pos: torch.Tensor, item_pos: to
     return mlp_forward(combined, mlp_weights(state))
 
 
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def basic_ncf_forward_indexed_bf16(state: State, user_pos: torch.Tensor, item_pos: torch.Tensor) -> torch.Tensor:
+    """BASELINE config 5 arithmetic (no reference counterpart — the reference is fp32 only): tables and MLP weight
+    matrices rounded to bf16 (round-to-nearest-even), products accumulated in fp32, hidden activations rounded to
+    bf16 where they feed the next matrix product, biases / the final 1-wide layer / the output in fp32.
+    Evaluated in fp64 on the rounded operands so that only the accumulation order differs from the GPU."""
+    tu = _bf16(embedding_table(state["user_embeddings.0.weight"], state["user_embeddings.0.bias"]))
+    ti = _bf16(embedding_table(state["item_embeddings.0.weight"], state["item_embeddings.0.bias"]))
+    layers = mlp_weights(state)
+    h = torch.cat((tu[user_pos], ti[item_pos]), dim=1).double()
+    for li, (w, b) in enumerate(layers[:-1]):
+        h = torch.relu(h @ _bf16(w).double().t() + b.double())
+        if li < len(layers) - 2:
+            h = _bf16(h.float()).double()  # feeds the next MFMA as a bf16 operand
+    w, b = layers[-1]
+    return (h @ w.double().t() + b.double()).float()
+
+
 def mf_forward(state: State, X_user: torch.Tensor, X_item: torch.Tensor) -> torch.Tensor:
     """models/mf.py:28-32 — dot product of the two embeddings, shape (B, 1)."""
     user_emb = F.linear(X_user, state["user_embeddings.0.weight"], state["user_embeddings.0.bias"])
