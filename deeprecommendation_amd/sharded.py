@@ -67,9 +67,9 @@ class RowShardedTable:
 
     def lookup_unique(self, idx: torch.Tensor):
         """Returns (rows_of_unique_ids (n_unique, E), inverse (B,) int64) with rows[inverse[p]] == table[idx[p]]."""
-        uniq, inverse = torch.unique(idx, return_inverse=True)  # sorted ascending -> contiguous owner buckets
         if self.world == 1:
-            return self.ops.gather_rows(self.local, uniq.contiguous()), inverse.contiguous()
+            return self.local, idx.contiguous()  # nothing to exchange: the scoring kernel gathers from the table itself
+        uniq, inverse = torch.unique(idx, return_inverse=True)  # sorted ascending -> contiguous owner buckets
         dev = idx.device
         owner = torch.div(uniq, self.rows_per_rank, rounding_mode="floor")
         send_counts = torch.bincount(owner, minlength=self.world)
