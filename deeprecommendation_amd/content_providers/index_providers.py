@@ -1,0 +1,180 @@
+"""Index-returning counterparts of the reference's concrete providers (src/content_providers/*.py).
+
+The reference builds a dense one-hot row per sample with sklearn's LabelBinarizer re-fitted per batch
+(src/util.py:5-10, one_hot_provider.py:17-21).  At 1 M users that row is 4 MB per sample; the table path needs only
+the COLUMN of the 1 — the rank of the id among the sorted unique ids (one_hot_provider.py:14-15, LabelBinarizer's
+``classes_`` order).  These providers return that position (int64) and keep the reference's method names, so
+datasets / eval loops written against ``ContentProvider`` keep working.
+"""
+import numpy as np
+import torch
+
+from ..neural_collaborative_filtering.content_providers import ContentProvider, DynamicContentProvider, GraphContentProvider
+from ..neural_collaborative_filtering.models.attention_ncf import SparseRatings
+from ..neural_collaborative_filtering.models.gnn_ncf import GraphData
+
+
+def _positions(sorted_ids: np.ndarray, ids) -> np.ndarray:
+    ids = np.atleast_1d(np.asarray(ids))
+    pos = np.searchsorted(sorted_ids, ids)
+    bad = (pos >= len(sorted_ids)) | (sorted_ids[np.minimum(pos, len(sorted_ids) - 1)] != ids)
+    if bad.any():
+        raise KeyError(f"unknown id(s): {ids[bad][:5].tolist()}")
+    return pos.astype(np.int64)
+
+
+class IndexProvider(ContentProvider):
+    """Same id universe as the reference's OneHotProvider (all ids of the full utility matrix, sorted), but
+    ``get_*_profile`` returns int64 positions instead of one-hot rows."""
+
+    def __init__(self, user_ids, item_ids):
+        self.all_item_ids = np.array(sorted(np.unique(np.asarray(item_ids))))
+        self.all_user_ids = np.array(sorted(np.unique(np.asarray(user_ids))))
+
+    @classmethod
+    def from_csv(cls, full_matrix_csv):
+        import pandas as pd
+        m = pd.read_csv(full_matrix_csv)
+        return cls(m['userId'].values, m['movieId'].values)
+
+    def get_item_profile(self, itemID):
+        return _positions(self.all_item_ids, itemID)
+
+    def get_user_profile(self, userID):
+        return _positions(self.all_user_ids, userID)
+
+    def get_num_items(self):
+        return len(self.all_item_ids)
+
+    def get_num_users(self):
+        return len(self.all_user_ids)
+
+    def get_item_feature_dim(self):
+        return self.get_num_items()
+
+
+class OneHotProvider(IndexProvider):
+    """Dense one-hot rows like the reference's OneHotProvider (small scale only), without sklearn."""
+
+    def _onehot(self, pos, n):
+        out = np.zeros((len(pos), n), dtype=np.int64)
+        out[np.arange(len(pos)), pos] = 1
+        return out
+
+    def get_item_profile(self, itemID):
+        return self._onehot(_positions(self.all_item_ids, itemID), self.get_num_items())
+
+    def get_user_profile(self, userID):
+        return self._onehot(_positions(self.all_user_ids, userID), self.get_num_users())
+
+
+class IndexGraphProvider(GraphContentProvider):
+    """Vectorised counterpart of GraphProvider + create_graph (graph_providers.py:10-118) with one-hot node features
+    (OneHotGraphProvider): items are nodes 0..I-1 in sorted id order, user node id = I + rank (:79-80); edge
+    user->item weighs ``rating - (mean_user + 2.5)/2`` and item->user ``rating - (mean_item + 2.5)/2`` (:31-47);
+    ``binary=True`` keeps only edges with rating >= that neutral value and drops the weights."""
+
+    def __init__(self, all_user_ids, all_item_ids, inter_users, inter_items, inter_ratings, binary=False):
+        self.binary = binary
+        self.all_items = np.array(sorted(np.unique(np.asarray(all_item_ids))))
+        self.all_users = np.array(sorted(np.unique(np.asarray(all_user_ids))))
+        I = len(self.all_items)
+        u = np.asarray(inter_users)
+        it = np.asarray(inter_items)
+        r = np.asarray(inter_ratings, dtype=np.float64)
+        upos = _positions(self.all_users, u)
+        ipos = _positions(self.all_items, it)
+        # per-user / per-item mean rating over THESE interactions (groupby().mean(), :16-17)
+        usum = np.bincount(upos, weights=r, minlength=len(self.all_users))
+        ucnt = np.maximum(np.bincount(upos, minlength=len(self.all_users)), 1)
+        isum = np.bincount(ipos, weights=r, minlength=I)
+        icnt = np.maximum(np.bincount(ipos, minlength=I), 1)
+        user_avg = ((usum / ucnt)[upos] + 2.5) / 2
+        item_avg = ((isum / icnt)[ipos] + 2.5) / 2
+        unode = upos + I
+        k1 = np.ones(len(r), bool) if not binary else r >= user_avg
+        k2 = np.ones(len(r), bool) if not binary else r >= item_avg
+        self.graph = GraphData(
+            item_features=None, user_features=None,
+            user2item_edge_index=torch.from_numpy(np.stack([unode[k1], ipos[k1]])),
+            item2user_edge_index=torch.from_numpy(np.stack([ipos[k2], unode[k2]])),
+            user2item_edge_attr=None if binary else torch.from_numpy((r - user_avg)[k1]).float(),
+            item2user_edge_attr=None if binary else torch.from_numpy((r - item_avg)[k2]).float(),
+            num_items=I, num_users=len(self.all_users))
+
+    def get_num_items(self):
+        return len(self.all_items)
+
+    def get_num_users(self):
+        return len(self.all_users)
+
+    def get_item_dim(self):
+        return self.get_num_items()
+
+    def get_user_dim(self):
+        return self.get_num_users()
+
+    def get_user_nodeID(self, userID):
+        pos = _positions(self.all_users, userID) + self.get_num_items()
+        return pos if np.ndim(userID) else int(pos[0])
+
+    def get_item_nodeID(self, itemID):
+        pos = _positions(self.all_items, itemID)
+        return pos if np.ndim(itemID) else int(pos[0])
+
+    def get_graph(self) -> GraphData:
+        return self.graph
+
+
+class SparseDynamicProvider(DynamicContentProvider):
+    """Counterpart of DynamicProfilesProvider (dynamic_profiles_provider.py:10-73) over in-memory arrays.
+
+    ``item_ids`` (I,), ``item_features`` (I, F); per user: arrays of rated item ids (sorted by id, the ordering the
+    reference relies on, :64-66), ratings and the user's mean rating.  ``collate_interacted_items`` emits the same
+    6-tuple; with ``sparse=True`` the user matrix is a SparseRatings (CSR) instead of the dense (B, I) float matrix.
+    Values are ``rating - (mean + 2.5)/2`` (:66); entries equal to 0.0 are dropped exactly as the reference's
+    ``user_matrix != 0`` does (attention_ncf.py:158).
+    """
+
+    def __init__(self, item_ids, item_features, user_ids, user_rated_items, user_ratings, user_mean_ratings, sparse=True):
+        order = np.argsort(np.asarray(item_ids))
+        self.item_ids = np.asarray(item_ids)[order]
+        self.features = torch.as_tensor(np.asarray(item_features)[order], dtype=torch.float32)
+        self.user_pos = {u: k for k, u in enumerate(np.asarray(user_ids).tolist())}
+        self.user_rated_items = [np.asarray(x) for x in user_rated_items]
+        self.user_ratings = [np.asarray(x, dtype=np.float64) for x in user_ratings]
+        self.user_mean = np.asarray(user_mean_ratings, dtype=np.float64)
+        self.sparse = sparse
+
+    def get_item_profile(self, itemID):
+        return self.features[torch.from_numpy(_positions(self.item_ids, itemID))]
+
+    def get_num_items(self):
+        return len(self.item_ids)
+
+    def get_num_users(self):
+        return len(self.user_pos)
+
+    def get_item_feature_dim(self):
+        return self.features.shape[1]
+
+    def collate_interacted_items(self, batch, for_ranking: bool, ignore_ratings=False):
+        users, cand, third = zip(*batch)
+        cand_ids = np.asarray(cand)
+        candidate_items = self.get_item_profile(cand_ids)
+        targets_or_items2 = self.get_item_profile(np.asarray(third)) if for_ranking else torch.as_tensor(np.asarray(third), dtype=torch.float32)
+        ups = [self.user_pos[u] for u in users]
+        rated_ids = np.unique(np.concatenate([self.user_rated_items[p] for p in ups]))  # sorted (:59)
+        cols, vals, counts = [], [], []
+        for p in ups:
+            c = np.searchsorted(rated_ids, self.user_rated_items[p])
+            v = np.ones(len(c)) if ignore_ratings else self.user_ratings[p] - (self.user_mean[p] + 2.5) / 2
+            v = v.astype(np.float32)
+            keep = v != 0
+            cols.append(c[keep]); vals.append(v[keep]); counts.append(int(keep.sum()))
+        rowptr = torch.zeros(len(ups) + 1, dtype=torch.int64)
+        rowptr[1:] = torch.cumsum(torch.as_tensor(counts), 0)
+        ratings = SparseRatings(rowptr, torch.as_tensor(np.concatenate(cols), dtype=torch.int32),
+                                torch.as_tensor(np.concatenate(vals), dtype=torch.float32), len(rated_ids))
+        user_matrix = ratings if self.sparse else ratings.to_dense(ratings.val)
+        return cand_ids, rated_ids, candidate_items, self.get_item_profile(rated_ids), user_matrix, targets_or_items2

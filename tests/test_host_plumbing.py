@@ -1,0 +1,153 @@
+"""CPU tests of the host-side mirror: providers, datasets, eval metrics, model contract (no GPU compute)."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import load_golden
+from deeprecommendation_amd.content_providers.index_providers import (IndexGraphProvider, IndexProvider, OneHotProvider,
+                                                                        SparseDynamicProvider)
+from deeprecommendation_amd.neural_collaborative_filtering import eval as E
+from deeprecommendation_amd.neural_collaborative_filtering.datasets.fixed_datasets import FixedPointwiseDataset
+from deeprecommendation_amd.neural_collaborative_filtering.datasets.gnn_datasets import GraphPointwiseDataset
+from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF, SparseRatings
+from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphNCF
+from deeprecommendation_amd.neural_collaborative_filtering.util import build_MLP_layers, load_model
+
+
+def test_index_provider_matches_label_binarizer_columns():
+    """Position == column of the 1 in the reference's one-hot row (src/util.py:5-10: LabelBinarizer fitted on the
+    sorted unique ids)."""
+    from sklearn.preprocessing import LabelBinarizer
+    rng = np.random.default_rng(0)
+    ids = rng.choice(10_000, 300, replace=False)
+    p = IndexProvider(user_ids=ids, item_ids=ids[:50])
+    q = rng.choice(ids, 64)
+    lb = LabelBinarizer().fit(np.array(sorted(np.unique(ids))))
+    assert np.array_equal(p.get_user_profile(tuple(q)), lb.transform(q).argmax(1))
+    oh = OneHotProvider(user_ids=ids, item_ids=ids[:50])
+    assert np.array_equal(oh.get_user_profile(tuple(q)), lb.transform(q))
+    with pytest.raises(KeyError):
+        p.get_user_profile((123456,))
+    assert p.get_num_users() == 300 and p.get_num_items() == 50 and p.get_item_feature_dim() == 50
+
+
+def test_eval_ranking_matches_reference_goldens():
+    _, a, _ = load_golden("g5_eval_ranking")
+    df = pd.DataFrame({"userId": a["userId"], "rating": a["rating"], "prediction": a["prediction"]})
+    for k, key in ((5, "ndcg5"), (10, "ndcg10")):
+        nd, adj = E.eval_ranking(df, cutoff=k)
+        assert abs(nd - a[key][0]) < 1e-12 and abs(adj - a[key][1]) < 1e-12
+    _, c, _ = load_golden("cfg1_basic_ml1m")
+    df = pd.DataFrame({"userId": c["user_pos"] + 1, "rating": c["rating"], "prediction": c["out"].reshape(-1).astype(np.float64)})
+    for k in (5, 10, 20):
+        nd, adj = E.eval_ranking(df, cutoff=k)
+        assert abs(nd - c[f"ndcg{k}"][0]) < 1e-12 and abs(adj - c[f"ndcg{k}"][1]) < 1e-12
+
+
+def _loop_graph(users, items, ratings, all_users, all_items, binary):
+    """Straight restatement of create_graph's loop (graph_providers.py:19-47) for the test."""
+    all_items, all_users = sorted(set(all_items)), sorted(set(all_users))
+    inode = {i: k for k, i in enumerate(all_items)}
+    unode = {u: len(all_items) + k for k, u in enumerate(all_users)}
+    df = pd.DataFrame({"userId": users, "movieId": items, "rating": ratings})
+    um, im = df.groupby("userId")["rating"].mean(), df.groupby("movieId")["rating"].mean()
+    e1, a1, e2, a2 = [], [], [], []
+    for u, i, r in zip(users, items, ratings):
+        ua, ia = (um.loc[u] + 2.5) / 2, (im.loc[i] + 2.5) / 2
+        if not binary or r >= ua:
+            e1.append([unode[u], inode[i]]); a1.append(r - ua)
+        if not binary or r >= ia:
+            e2.append([inode[i], unode[u]]); a2.append(r - ia)
+    return np.array(e1).T, np.array(a1), np.array(e2).T, np.array(a2)
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_index_graph_provider_matches_reference_loop(binary):
+    rng = np.random.default_rng(1)
+    users = rng.integers(100, 140, 300)
+    items = rng.integers(7, 30, 300) * 3
+    ratings = rng.integers(1, 11, 300) * 0.5
+    gp = IndexGraphProvider(np.arange(100, 145), np.arange(0, 100), users, items, ratings, binary=binary)
+    e1, a1, e2, a2 = _loop_graph(users, items, ratings, np.arange(100, 145), np.arange(0, 100), binary)
+    g = gp.get_graph()
+    assert np.array_equal(g.user2item_edge_index.numpy(), e1) and np.array_equal(g.item2user_edge_index.numpy(), e2)
+    if binary:
+        assert g.user2item_edge_attr is None and g.item2user_edge_attr is None
+    else:
+        assert np.allclose(g.user2item_edge_attr.numpy(), a1, rtol=0, atol=1e-6)
+        assert np.allclose(g.item2user_edge_attr.numpy(), a2, rtol=0, atol=1e-6)
+    assert gp.get_user_nodeID(100) == 100 and gp.get_item_nodeID(0) == 0   # items first, users after (:79-80)
+    assert g.num_items == 100 and g.num_users == 45
+
+
+def test_sparse_dynamic_provider_matches_dense_reference_form():
+    rng = np.random.default_rng(2)
+    item_ids = np.arange(1000, 1040)
+    feats = rng.random((40, 9)).astype(np.float32)
+    user_ids = [5, 9, 11]
+    rated = [np.sort(rng.choice(item_ids, n, replace=False)) for n in (6, 0, 13)]
+    ratings = [rng.integers(1, 11, len(r)) * 0.5 for r in rated]
+    means = [float(np.mean(r)) if len(r) else 3.0 for r in ratings]
+    ratings[0][2] = (means[0] + 2.5) / 2  # a rating exactly at the neutral value -> entry 0.0 -> dropped (:158)
+    p = SparseDynamicProvider(item_ids, feats, user_ids, rated, ratings, means, sparse=True)
+    batch = [(5, 1003, 4.0), (9, 1001, 2.5), (11, 1010, 5.0), (5, 1039, 1.0)]
+    cand_ids, rated_ids, cand, rated_feats, um, y = p.collate_interacted_items(batch, for_ranking=False)
+    assert isinstance(um, SparseRatings)
+    # dense restatement of dynamic_profiles_provider.py:55-71
+    ref_rated = np.sort(np.unique(np.concatenate([rated[0], rated[1], rated[2], rated[0]])))
+    dense = np.zeros((4, len(ref_rated)), dtype=np.float32)
+    for row, uix in enumerate([0, 1, 2, 0]):
+        dense[row, np.searchsorted(ref_rated, rated[uix])] = (ratings[uix] - (means[uix] + 2.5) / 2).astype(np.float32)
+    assert np.array_equal(rated_ids, ref_rated)
+    assert torch.equal(um.to_dense(um.val), torch.from_numpy(dense))
+    assert int(um.rowptr[2] - um.rowptr[1]) == 0                      # user without ratings: empty row
+    assert torch.equal(cand, torch.from_numpy(feats[[3, 1, 10, 39]]))
+    assert torch.equal(rated_feats, torch.from_numpy(feats[ref_rated - 1000]))
+    p2 = SparseDynamicProvider(item_ids, feats, user_ids, rated, ratings, means, sparse=False)
+    assert torch.equal(p2.collate_interacted_items(batch, False)[4], torch.from_numpy(dense))
+
+
+def test_dataset_collate_and_model_contract(tmp_path):
+    df = pd.DataFrame({"userId": [3, 5, 3, 9], "movieId": [10, 20, 20, 10], "rating": [4.0, 2.5, 3.0, 5.0]})
+    df.to_csv(tmp_path / "test.csv", index=False)
+    prov = IndexProvider([3, 5, 9], [10, 20])
+    ds = FixedPointwiseDataset(str(tmp_path / "test"), prov)       # file name without '.csv', as the reference passes it
+    assert len(ds) == 4 and ds[1] == (5, 20, 2.5)
+    u, i, y = ds.use_collate()([ds[k] for k in range(4)])
+    assert u.dtype == torch.int64 and u.tolist() == [0, 1, 0, 2] and i.tolist() == [0, 1, 1, 0] and y.dtype == torch.float32
+    m = BasicNCF(item_dim=2, user_dim=3, item_emb=8, user_emb=8, mlp_dense_layers=[16])
+    assert m.is_dataset_compatible(FixedPointwiseDataset) and not m.is_dataset_compatible(GraphPointwiseDataset)
+    RefLike = type("FixedRankingDataset", (), {})                   # the reference's class, matched by name
+    assert m.is_dataset_compatible(RefLike)
+    assert GraphNCF(2, 3, 2, True, node_emb=8).is_dataset_compatible(GraphPointwiseDataset)
+    # checkpoint format [state_dict, kwargs] round-trips (reference models/base.py:18-19, util.py:21-34)
+    m.save_model(tmp_path / "m.pt")
+    m2 = load_model(tmp_path / "m.pt", BasicNCF)
+    assert m2.kwargs == m.kwargs and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    # training step stays on differentiable torch ops and works on CPU
+    m.train()
+    out = m(u, i)
+    ds.calculate_loss(out, y).backward()
+    assert m.user_embeddings[0].weight.grad is not None
+    keys = list(build_MLP_layers(10, [8, 4], dropout_rate=None).state_dict().keys())
+    assert keys == ["0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias"]
+
+
+def test_attention_and_graph_training_paths_run_on_cpu():
+    torch.manual_seed(0)
+    att = AttentionNCF(item_dim=12, item_emb=8, user_emb=8, att_dense=4, mlp_dense_layers=[8], message_dropout=0.2).train()
+    cand, rated = torch.rand(5, 12), torch.rand(7, 12)
+    um = torch.randn(5, 7) * (torch.rand(5, 7) < 0.5)
+    out = att(cand, rated, um)
+    out.sum().backward()
+    assert out.shape == (5, 1) and att.ItemEmbeddings[0].weight.grad is not None
+    gp = IndexGraphProvider(np.arange(6), np.arange(4), [0, 1, 2, 3, 4, 5, 0], [0, 1, 2, 3, 0, 1, 2], [4.0, 3, 5, 1, 2, 4.5, 3.5])
+    g = GraphNCF(item_dim=4, user_dim=6, num_gnn_layers=2, hetero=True, node_emb=8, mlp_dense_layers=[8],
+                 message_dropout=0.1, node_dropout=0.1).train()
+    users = torch.tensor([gp.get_user_nodeID(0), gp.get_user_nodeID(3)])
+    items = torch.tensor([gp.get_item_nodeID(0), gp.get_item_nodeID(3)])
+    out = g(gp.get_graph(), users, items, torch.device("cpu"))
+    out.sum().backward()
+    assert out.shape == (2, 1) and g.gnn_convs[0].user2item_W[0].weight.grad is not None
