@@ -6,11 +6,27 @@
 // Algorithmic bytes per pair: (EA + EB) * elt read + 16 B of indices + (EA + EB) * elt written.
 #include "ncf_common.h"
 
+#ifndef NCF_G_UNROLL
+#define NCF_G_UNROLL 1        // wave steps per wave; measured (cfg 2, A/B): 4 -> 13.3 us, 2 -> 12.8, 1 -> 13.1; with NT stores 2 -> 12.33, 1 -> 12.28
+#endif
+#ifndef NCF_G_NT_STORE
+#define NCF_G_NT_STORE 1      // non-temporal stores for the streamed output rows (13.3 -> 13.0 us alone; NT LOADS are slower: 15.5)
+#endif
+#ifndef NCF_G_NT_LOAD
+#define NCF_G_NT_LOAD 0       // 1: non-temporal loads for the table rows
+#endif
+#ifndef NCF_G_THREADS
+#define NCF_G_THREADS 256     // workgroup size of the vector gather kernel
+#endif
+#ifndef NCF_G_MAXBLOCKS
+#define NCF_G_MAXBLOCKS (256 * 128)
+#endif
+
 namespace ncf {
 
 // LPP lanes cooperate on one pair; a wave moves 64 / LPP pairs per step and UNROLL steps are in flight.
 template <int LPP, int UNROLL>
-__global__ __launch_bounds__(256) void gather_concat_vec16(
+__global__ __launch_bounds__(NCF_G_THREADS) void gather_concat_vec16(
     const char* __restrict__ tabA, int64_t rowsA, int64_t ldA_bytes,
     const char* __restrict__ tabB, int64_t rowsB, int64_t ldB_bytes,
     const int64_t* __restrict__ idxA, const int64_t* __restrict__ idxB,
@@ -36,12 +52,10 @@ __global__ __launch_bounds__(256) void gather_concat_vec16(
             char* o = out + p * ldOut_bytes;
             for (int c = sub; c < cpp; c += LPP) {
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (c < chunksA) {
-                    if (okA) v = *reinterpret_cast<const u32x4*>(ra + (int64_t)c * 16);
-                } else {
-                    if (okB) v = *reinterpret_cast<const u32x4*>(rb + (int64_t)(c - chunksA) * 16);
-                }
-                *reinterpret_cast<u32x4*>(o + (int64_t)c * 16) = v;
+                const u32x4* src = reinterpret_cast<const u32x4*>(c < chunksA ? ra + (int64_t)c * 16 : rb + (int64_t)(c - chunksA) * 16);
+                if (c < chunksA ? okA : okB) v = NCF_G_NT_LOAD ? __builtin_nontemporal_load(src) : *src;
+                if (NCF_G_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(o + (int64_t)c * 16));
+                else *reinterpret_cast<u32x4*>(o + (int64_t)c * 16) = v;
             }
         }
     }
@@ -115,13 +129,13 @@ template <int LPP>
 static void launch_vec16(const char* tabA, int64_t rowsA, int64_t ldA_b, const char* tabB, int64_t rowsB, int64_t ldB_b,
                          const int64_t* idxA, const int64_t* idxB, int64_t B, int cA, int cB, char* out, int64_t ldO_b,
                          int32_t* oob, hipStream_t s) {
-    constexpr int UNROLL = 4;
+    constexpr int UNROLL = NCF_G_UNROLL;
     constexpr int PPW = kWave / LPP;
-    const int64_t pairs_per_block = (int64_t)4 * PPW * UNROLL;
+    const int64_t pairs_per_block = (int64_t)(NCF_G_THREADS / 64) * PPW * UNROLL;
     int64_t blocks = (B + pairs_per_block - 1) / pairs_per_block;
-    if (blocks > 256 * 32) blocks = 256 * 32;  // 8 blocks/CU x 256 CUs x 4 rounds; grid-stride beyond
+    if (blocks > NCF_G_MAXBLOCKS) blocks = NCF_G_MAXBLOCKS;  // grid-stride beyond
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((gather_concat_vec16<LPP, UNROLL>), dim3((unsigned)blocks), dim3(256), 0, s, tabA, rowsA, ldA_b,
+    hipLaunchKernelGGL((gather_concat_vec16<LPP, UNROLL>), dim3((unsigned)blocks), dim3(NCF_G_THREADS), 0, s, tabA, rowsA, ldA_b,
                        tabB, rowsB, ldB_b, idxA, idxB, B, cA, cB, out, ldO_b, oob);
 }
 

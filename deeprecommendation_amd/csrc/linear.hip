@@ -114,9 +114,149 @@ __global__ __launch_bounds__(256) void rowdot_f32_kernel(const float* __restrict
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-streaming GEMM for N in {32, 64, 128, 256}: no LDS staging at all.  One wave owns 32 rows of A and ALL N output
+// columns (NT = N/32 accumulator tiles).  Lane (i, h) reads the 16-byte chunk k = 8q + 4h .. +3 of ITS row of A
+// (A operand) and of row 32nt + i of W (B operand) straight from global memory — the same identical-k-permutation
+// trick as the fused kernel, so one 16-byte load per operand feeds 4 MFMAs; W is small and stays L1/L2 resident.
+// Output registers hold rows, lanes hold columns -> every store instruction writes 128 contiguous bytes per row.
+// Skinny problems (few row tiles, long K: the F = 2094 candidate Linear of AttentionNCF) split K over the KS waves
+// of a tile and add the slices through LDS in slice order (deterministic).
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // rows of A may be only 4-byte aligned
+
+template <int NT>
+struct RsFrag {
+    f32x4 a;
+    f32x4 w[NT];
+};
+
+template <int NT>
+__device__ __forceinline__ void rs_load(RsFrag<NT>& f, const float* arow, const float* const (&wrow)[NT], int q) {
+    f.a = *reinterpret_cast<const f32x4u*>(arow + 8 * q);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) f.w[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt] + 8 * q);
+}
+
+template <int NT>
+__device__ __forceinline__ void rs_mma(const RsFrag<NT>& f, f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j], f.w[nt][j], acc[nt], 0, 0, 0);
+}
+
+template <int NT, int KS, bool RELU>
+__global__ __launch_bounds__(256) void linear_rs_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                        int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
+                                                        int64_t ldc, int64_t M, int K) {
+    __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 4 * NT * 16 * 64 : 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * (4 / KS) + wave / KS;
+    const int ks = wave % KS;
+    const bool tile_ok = tile * 32 < M;  // wave-uniform
+    const int64_t m = tile * 32 + i;
+    const float* arow = A + (m < M ? m : (M - 1)) * lda + 4 * h;
+    const float* wrow[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (int64_t)(32 * nt + i) * ldw + 4 * h;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    const int Q = K / 8;
+    const int qlo = (int)((int64_t)ks * Q / KS), qhi = (int)((int64_t)(ks + 1) * Q / KS);
+    if (tile_ok) {
+        RsFrag<NT> f0, f1;
+        int q = qlo;
+        if (q < qhi) rs_load<NT>(f0, arow, wrow, q);
+        for (; q + 1 < qhi; q += 2) {  // two-stage register pipeline: the next group's loads fly under this group's MFMAs
+            rs_load<NT>(f1, arow, wrow, q + 1);
+            rs_mma<NT>(f0, acc);
+            if (q + 2 < qhi) rs_load<NT>(f0, arow, wrow, q + 2);
+            rs_mma<NT>(f1, acc);
+        }
+        if (q < qhi) rs_mma<NT>(f0, acc);
+        if ((K & 7) && ks == KS - 1) {  // ragged tail of K: guarded scalar loads, zero fill
+            RsFrag<NT> t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = 8 * Q + 4 * h + j < K;
+                t.a[j] = ok ? arow[8 * Q + j] : 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) t.w[nt][j] = ok ? wrow[nt][8 * Q + j] : 0.f;
+            }
+            rs_mma<NT>(t, acc);
+        }
+    }
+    if (KS > 1) {
+        float* mine = red + (size_t)wave * (NT * 16 * 64);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(nt * 16 + r) * 64 + lane] = acc[nt][r];
+        __syncthreads();
+        if (ks != 0) return;
+#pragma unroll
+        for (int s = 1; s < KS; ++s) {
+            const float* other = red + (size_t)(wave + s) * (NT * 16 * 64);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] += other[(nt * 16 + r) * 64 + lane];
+        }
+    }
+    if (!tile_ok) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = 32 * nt + i;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t gm = tile * 32 + acc_row(r, h);
+            if (gm < M) {
+                float v = acc[nt][r] + bv;
+                if (RELU) v = fmaxf(v, 0.f);
+                C[gm * ldc + n] = v;
+            }
+        }
+    }
+}
+
+template <int NT, int KS>
+static void launch_rs(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                      int64_t M, int K, bool relu, hipStream_t s) {
+    const int64_t tiles = (M + 31) / 32;
+    const unsigned blocks = (unsigned)((tiles + (4 / KS) - 1) / (4 / KS));
+    if (relu) hipLaunchKernelGGL((linear_rs_kernel<NT, KS, true>), dim3(blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
+    else hipLaunchKernelGGL((linear_rs_kernel<NT, KS, false>), dim3(blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
+}
+
+template <int NT>
+static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                         int64_t M, int K, bool relu, hipStream_t s) {
+    const int64_t tiles = (M + 31) / 32;
+    if constexpr (NT <= 4) {
+        if (tiles <= 1024 && K >= 64) return launch_rs<NT, 4>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
+        if (tiles <= 2048 && K >= 32) return launch_rs<NT, 2>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
+    }
+    launch_rs<NT, 1>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
+}
+
 static int launch_linear(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                          int64_t M, int N, int K, bool relu, hipStream_t s) {
     if (M == 0) return NCF_OK;
+    if (K >= 8 && (N == 32 || N == 64 || N == 128 || N == 256)) {
+        if (N == 32) launch_rs_nt<1>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
+        else if (N == 64) launch_rs_nt<2>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
+        else if (N == 128) launch_rs_nt<4>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
+        else launch_rs_nt<8>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
+        return check_launch("linear_rs_f32");
+    }
     if (N <= 8) {
         int64_t blocks = (M * N + 15) / 16;
         if (blocks > 16384) blocks = 16384;

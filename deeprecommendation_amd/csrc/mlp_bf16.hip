@@ -16,7 +16,13 @@
 #include "ncf_common.h"
 
 #ifndef NCF_BF16_X_DEPTH
-#define NCF_BF16_X_DEPTH 8   // gathered-row prefetch ring, in 16-wide k-steps
+#define NCF_BF16_X_DEPTH 4   // gathered-row prefetch ring, in 16-wide k-steps (measured: 4 -> 20.6 us, 8 -> 21.3, 16 -> 21.7)
+#endif
+#ifndef NCF_BF16_MSTEP
+#define NCF_BF16_MSTEP 4     // 16-wide k-steps per weight slab (= per barrier); measured 2 -> 20.8 us, 4 -> 19.3 us
+#endif
+#ifndef NCF_BF16_ABLATE
+#define NCF_BF16_ABLATE 0    // diagnostics: 1 = no gathered-row loads, 2 = no weight slab copies / barriers
 #endif
 
 namespace ncf {
@@ -62,8 +68,9 @@ __global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
     constexpr int NT1 = N1 / 32, Q1 = K0 / 16;   // layer 1: Q1 k-steps of 16
     constexpr int NT2 = N2 / 32, Q2 = N1 / 16;   // layer 2
     constexpr int XD = NCF_BF16_X_DEPTH < Q1 ? NCF_BF16_X_DEPTH : Q1;
-    constexpr int SLAB1 = 2 * NT1 * 1024;        // bytes per macro-step (2 k-steps) of layer 1
-    constexpr int SLAB2 = 2 * NT2 * 1024;
+    constexpr int MS = NCF_BF16_MSTEP;
+    constexpr int SLAB1 = MS * NT1 * 1024;       // bytes per macro-step (MS k-steps) of layer 1
+    constexpr int SLAB2 = MS * NT2 * 1024;
     constexpr int PIECES1 = SLAB1 / 1024 / 8;    // 1-KiB pieces per wave per slab
     constexpr int PIECES2 = (SLAB2 / 1024 + 7) / 8;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][SLAB1];
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
     // gathered-row ring: chunk of k-step q is requested XD steps ahead; plain loads survive the LDS barriers
     u32x4 x[XD];
 #pragma unroll
-    for (int t = 0; t < XD; ++t) x[t] = ldg16(xsrc(t));
+    for (int t = 0; t < XD; ++t) x[t] = (NCF_BF16_ABLATE == 1) ? u32x4{1u, 2u, 3u, 4u} : ldg16(xsrc(t));
 
     // first weight slab -> LDS buffer 0
     {
@@ -116,11 +123,11 @@ __global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
 
     // ---------------- layer 1 ----------------
 #pragma unroll
-    for (int t = 0; t < Q1 / 2; ++t) {
+    for (int t = 0; t < Q1 / MS; ++t) {
         const int cur = t & 1;
         // fetch the next slab (layer 1's next, or layer 2's first) into registers
         u32x4 nxt[PIECES1];
-        const bool more1 = t + 1 < Q1 / 2;
+        const bool more1 = t + 1 < Q1 / MS;
         if (more1 || N2 > 0) {
             const unsigned char* src = more1 ? reinterpret_cast<const unsigned char*>(a.Wp1) + (size_t)(t + 1) * SLAB1
                                              : reinterpret_cast<const unsigned char*>(a.Wp2);
@@ -132,18 +139,32 @@ __global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
                     if (more1 || piece * 1024 < SLAB2) nxt[i] = ldg16(src + piece * 1024 + lane * 16);
                 }
         }
+        // A fragments of k-step qq+1 are read from LDS while k-step qq's MFMAs run (register double buffer): hipcc's
+        // own schedule waits lgkmcnt(0) in front of every second MFMA, exposing the LDS latency ~100 times per tile.
+        u32x4 wa[2][NT1];
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-            const int q = 2 * t + qq;
+        for (int nt = 0; nt < NT1; ++nt) wa[0][nt] = *reinterpret_cast<const u32x4*>(&lds[cur][nt * 1024 + lane * 16]);
+#pragma unroll
+        for (int qq = 0; qq < MS; ++qq) {
+            const int q = MS * t + qq;
             u32x4 xr = x[q % XD];
             if (!(q < qa ? okA : okB)) xr = u32x4{0u, 0u, 0u, 0u};  // out-of-range row reads as zeros
-            if (q + XD < Q1) x[q % XD] = ldg16(xsrc(q + XD));
+            if (q + XD < Q1 && NCF_BF16_ABLATE != 1) x[q % XD] = ldg16(xsrc(q + XD));
             const bf16x8_t xb = as_bf16x8(xr);
 #pragma unroll
             for (int nt = 0; nt < NT1; ++nt) {
-                const bf16x8_t wa = as_bf16x8(*reinterpret_cast<const u32x4*>(&lds[cur][(qq * NT1 + nt) * 1024 + lane * 16]));
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa[qq & 1][nt]), xb, acc1[nt], 0, 0, 0);
+                if (qq + 1 < MS)
+                    wa[(qq + 1) & 1][nt] = *reinterpret_cast<const u32x4*>(&lds[cur][((qq + 1) * NT1 + nt) * 1024 + lane * 16]);
             }
+            if (qq + 1 < MS) {
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more1 || N2 > 0) {
             const int npieces = more1 ? PIECES1 : PIECES2;
@@ -176,13 +197,13 @@ __global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
                 acc2[nt][4 * g + 0] = bb[0]; acc2[nt][4 * g + 1] = bb[1];
                 acc2[nt][4 * g + 2] = bb[2]; acc2[nt][4 * g + 3] = bb[3];
             }
-        constexpr int T0 = (Q1 / 2) & 1;  // LDS buffer holding layer 2's first slab
+        constexpr int T0 = (Q1 / MS) & 1;  // LDS buffer holding layer 2's first slab
         // ---------------- layer 2 ----------------
 #pragma unroll
-        for (int t = 0; t < Q2 / 2; ++t) {
+        for (int t = 0; t < Q2 / MS; ++t) {
             const int cur = (T0 + t) & 1;
             u32x4 nxt[PIECES2];
-            const bool more = t + 1 < Q2 / 2;
+            const bool more = t + 1 < Q2 / MS;
             if (more) {
                 const unsigned char* src = reinterpret_cast<const unsigned char*>(a.Wp2) + (size_t)(t + 1) * SLAB2;
 #pragma unroll
@@ -191,14 +212,26 @@ __global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
                     if (piece * 1024 < SLAB2) nxt[i] = ldg16(src + piece * 1024 + lane * 16);
                 }
             }
+            u32x4 wa[2][NT2];
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int q = 2 * t + qq;  // k-step q = 2*kb + s'
+            for (int nt = 0; nt < NT2; ++nt) wa[0][nt] = *reinterpret_cast<const u32x4*>(&lds[cur][nt * 1024 + lane * 16]);
+#pragma unroll
+            for (int qq = 0; qq < MS; ++qq) {
+                const int q = MS * t + qq;  // k-step q = 2*kb + s'
 #pragma unroll
                 for (int nt = 0; nt < NT2; ++nt) {
-                    const bf16x8_t wa = as_bf16x8(*reinterpret_cast<const u32x4*>(&lds[cur][(qq * NT2 + nt) * 1024 + lane * 16]));
-                    acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, hb[q >> 1][q & 1], acc2[nt], 0, 0, 0);
+                    acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa[qq & 1][nt]), hb[q >> 1][q & 1], acc2[nt], 0, 0, 0);
+                    if (qq + 1 < MS)
+                        wa[(qq + 1) & 1][nt] = *reinterpret_cast<const u32x4*>(&lds[cur][((qq + 1) * NT2 + nt) * 1024 + lane * 16]);
                 }
+                if (qq + 1 < MS) {
+#pragma unroll
+                    for (int nt = 0; nt < NT2; ++nt) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (more) {
 #pragma unroll

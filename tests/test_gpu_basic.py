@@ -287,3 +287,32 @@ def test_score_fused_bf16_exact_small_integers(native, gpu):
     ref = O.mlp_forward(torch.cat((ta[ia], tb[ib]), 1).double(), [(w.double(), b.double()) for w, b in zip(ws, bs)])
     assert float(ref.abs().max()) < 2 ** 24
     assert torch.equal(out.cpu().double(), ref)
+
+
+def test_score_fused_out_of_range_rows_read_as_zeros(native, gpu):
+    """ABI contract: an out-of-range id never faults; that table's part of the row is zeros and the sticky flag is set."""
+    g = torch.Generator().manual_seed(0)
+    E, dims = 64, [128, 256, 128, 1]
+    ta = torch.randn(100, E, generator=g)
+    tb = torch.randn(50, E, generator=g)
+    ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(3)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(3)]
+    ia = torch.tensor([3, 100, 5, -1, 7])
+    ib = torch.tensor([1, 2, 50, 4, 49])
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-3)):
+        packed = native.PackedMLP([w.to(gpu) for w in ws], [b.to(gpu) for b in bs], dtype=dt)
+        if dt == torch.bfloat16:
+            packed_dims_ok = native.fused_supported(E, E, dims, dtype=dt)
+            assert packed_dims_ok
+        out = native.score_fused(ta.to(dt).to(gpu), ia.to(gpu), tb.to(dt).to(gpu), ib.to(gpu), packed)
+        xa = ta.to(dt).float()[ia.clamp(0, 99)] * ((ia >= 0) & (ia < 100)).float()[:, None]
+        xb = tb.to(dt).float()[ib.clamp(0, 49)] * ((ib >= 0) & (ib < 50)).float()[:, None]
+        wr = [w.to(dt).float() for w in ws[:2]] + [ws[2]]
+        h = torch.relu(torch.cat((xa, xb), 1).double() @ wr[0].double().t() + bs[0].double())
+        if dt == torch.bfloat16:
+            h = h.float().to(dt).double()
+        h = torch.relu(h @ wr[1].double().t() + bs[1].double())
+        ref = (h @ wr[2].double().t() + bs[2].double()).float()
+        assert_close(out, ref, rtol=tol)
+        with pytest.raises(IndexError):
+            native.check_oob(gpu)
