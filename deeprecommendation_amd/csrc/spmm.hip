@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const int64_t* __restrict
                     f32x4* sp = reinterpret_cast<f32x4*>(sum + row * ldsum + 4 * c);
                     *sp = *sp + acc;
                 }
-            } else {
+            } else if (partial) {
                 *reinterpret_cast<f32x4*>(partial + s * (int64_t)(4 * chunks) + 4 * c) = acc;
             }
         }
@@ -145,12 +145,12 @@ __global__ void scale_rows_kernel(const float* __restrict__ in, int64_t ldin, in
 template <int LPR>
 static void launch_spmm(const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col, const float* coef,
                         const float* z, int64_t Nz, int64_t ldz, int chunks, float* y, int64_t ldy, float* sum, int64_t ldsum,
-                        float* partial, hipStream_t s) {
+                        float* partial, bool fixup, hipStream_t s) {
     int64_t blocks = (n_seg + 3) / 4;
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL((spmm_seg_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, s, segptr, row_of, n_seg, col, coef, z, Nz,
                        ldz, chunks, y, ldy, sum, ldsum, partial);
-    if (row_of) {
+    if (row_of && fixup) {
         int64_t fb = (n_seg * LPR + 255) / 256;
         if (fb > 256 * 64) fb = 256 * 64;
         hipLaunchKernelGGL((spmm_fix_kernel<LPR>), dim3((unsigned)fb), dim3(256), 0, s, row_of, n_seg, chunks, partial, y, ldy, sum, ldsum);
@@ -163,23 +163,23 @@ using namespace ncf;
 
 extern "C" int ncf_spmm_csr(int dtype, const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col,
                             const float* coef, const void* z, int64_t Nz, int64_t ldz, int D, void* y, int64_t ldy,
-                            float* sum, int64_t ldsum, float* partial, ncf_stream_t stream) {
+                            float* sum, int64_t ldsum, float* partial, int fixup, ncf_stream_t stream) {
     if (dtype != NCF_F32) return fail(NCF_EUNSUPPORTED, "ncf_spmm_csr: fp32 only");
     if (!segptr || !z || !y || n_seg < 0 || D <= 0) return fail(NCF_EINVAL, "ncf_spmm_csr: bad argument");
     if (D % 4 || D > 256) return fail(NCF_EUNSUPPORTED, "ncf_spmm_csr: D = %d (need D %% 4 == 0 and D <= 256)", D);
     if (ldz % 4 || ldy % 4 || (sum && ldsum % 4) || !aligned16(z) || !aligned16(y) || (sum && !aligned16(sum)) || (partial && !aligned16(partial)))
         return fail(NCF_EINVAL, "ncf_spmm_csr: rows must be 16-byte aligned (ld %% 4 == 0)");
-    if (row_of && !partial) return fail(NCF_EINVAL, "ncf_spmm_csr: split rows need a partial buffer");
+    if (row_of && !partial && fixup) return fail(NCF_EINVAL, "ncf_spmm_csr: split rows need a partial buffer");
     if (n_seg == 0) return NCF_OK;
     if (!col) return fail(NCF_EINVAL, "ncf_spmm_csr: col is null");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = D / 4;
     const float* zf = (const float*)z;
     float* yf = (float*)y;
-    if (chunks <= 8) launch_spmm<8>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, s);
-    else if (chunks <= 16) launch_spmm<16>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, s);
-    else if (chunks <= 32) launch_spmm<32>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, s);
-    else launch_spmm<64>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, s);
+    if (chunks <= 8) launch_spmm<8>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s);
+    else if (chunks <= 16) launch_spmm<16>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s);
+    else if (chunks <= 32) launch_spmm<32>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s);
+    else launch_spmm<64>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s);
     return check_launch("ncf_spmm_csr");
 }
 

@@ -41,7 +41,7 @@ SIGNATURES = {
     "ncf_score_fused": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int,
                                  _c_int, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "ncf_spmm_csr": (_c_int, [_c_int, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p,
-                              _c_i64, _c_p, _c_p]),
+                              _c_i64, _c_p, _c_int, _c_p]),
     "ncf_degree_accumulate": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "ncf_edge_coef": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_scale_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, ctypes.c_float, _c_p, _c_i64, _c_p]),
@@ -273,7 +273,7 @@ def score_fused(tabA: torch.Tensor, idxA, tabB: Optional[torch.Tensor], idxB, pa
 # ------------------------------------------------------------------ K4 / K5
 def spmm_csr(segptr: torch.Tensor, row_of: Optional[torch.Tensor], col: torch.Tensor, coef: Optional[torch.Tensor],
              z: torch.Tensor, N: int, y: Optional[torch.Tensor] = None, acc_sum: Optional[torch.Tensor] = None,
-             partial: Optional[torch.Tensor] = None) -> torch.Tensor:
+             partial: Optional[torch.Tensor] = None, fixup: bool = True) -> torch.Tensor:
     lib = load_library()
     _dev(z, "z")
     Nz, D, ldz = _rows2d(z, "z")
@@ -287,8 +287,83 @@ def spmm_csr(segptr: torch.Tensor, row_of: Optional[torch.Tensor], col: torch.Te
     if row_of is not None and partial is None:
         partial = torch.empty((n_seg, D), dtype=torch.float32, device=z.device)
     _check(lib.ncf_spmm_csr(NCF_F32, _ptr(segptr), _ptr(row_of), n_seg, _ptr(col), _ptr(coef), _ptr(z), Nz, ldz, D, _ptr(y),
-                            y.stride(0), _ptr(acc_sum), 0 if acc_sum is None else acc_sum.stride(0), _ptr(partial), _stream(z)))
+                            y.stride(0), _ptr(acc_sum), 0 if acc_sum is None else acc_sum.stride(0), _ptr(partial),
+                            1 if fixup else 0, _stream(z)))
     return y
+
+
+class SegmentedCSR:
+    """A CSR-by-destination matrix prepared for ncf_spmm_csr: rows longer than ``seg_len`` edges are split into
+    segments (load balance), and rows with more than one segment are finished by re-applying the SAME kernel to the
+    partial sums with ``fan``-wide segments, level after level, until one segment per row is left — an ordered
+    log-depth tree (a hub item with 4 M in-edges: 8 k partials -> 125 -> 2 -> 1) instead of one lane group walking
+    8 k partials serially.  Deterministic: every level adds in index order."""
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, coef: Optional[torch.Tensor], seg_len: int = 512, fan: int = 64):
+        self.n_rows = rowptr.numel() - 1
+        self.col, self.coef = col, coef
+        dev = rowptr.device
+        counts = rowptr[1:] - rowptr[:-1]
+        self._build_tree(rowptr, counts, seg_len, fan)
+
+    @staticmethod
+    def _split(rowptr, row_ids, counts, seg_len):
+        """Segments of at most seg_len edges per row.  Returns (segptr, row_of or None, nseg per row)."""
+        dev = rowptr.device
+        nseg = torch.clamp((counts + seg_len - 1) // seg_len, min=1)
+        n = counts.numel()
+        if n == 0 or int(nseg.max()) == 1:
+            return rowptr, None, nseg
+        local_row = torch.repeat_interleave(torch.arange(n, device=dev), nseg)
+        first = torch.cumsum(nseg, 0) - nseg
+        local = torch.arange(local_row.numel(), device=dev) - first[local_row]
+        segptr = torch.empty(local_row.numel() + 1, dtype=torch.int64, device=dev)
+        segptr[:-1] = rowptr[local_row] + local * seg_len
+        segptr[-1] = rowptr[-1]
+        return segptr, row_ids[local_row].to(torch.int32).contiguous(), nseg
+
+    def _build_tree(self, rowptr, counts, seg_len, fan):
+        dev = rowptr.device
+        self.levels = []
+        row_ids = torch.arange(self.n_rows, device=dev)
+        segptr, row_of, nseg = self._split(rowptr, row_ids, counts, seg_len)
+        self.levels.append((segptr, row_of, None))
+        while row_of is not None:
+            # segments of this level that belong to multi-segment rows are the next level's "edges"
+            local_row = torch.repeat_interleave(torch.arange(nseg.numel(), device=dev), nseg)
+            multi_seg = (nseg > 1)[local_row]
+            edge_ids = torch.nonzero(multi_seg).flatten()                 # ids into this level's partial buffer
+            keep_rows = nseg > 1
+            row_ids = row_ids[keep_rows]
+            counts = nseg[keep_rows]
+            rp = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
+            rp[1:] = torch.cumsum(counts, 0)
+            segptr, row_of, nseg = self._split(rp, row_ids, counts, fan)
+            if row_of is None:  # every remaining row fits one segment: the kernel still needs the row map
+                row_of_last = row_ids.to(torch.int32).contiguous()
+                self.levels.append((segptr, row_of_last, edge_ids.to(torch.int32).contiguous()))
+                break
+            self.levels.append((segptr, row_of, edge_ids.to(torch.int32).contiguous()))
+        self._partials = {}
+
+    def spmm(self, z: torch.Tensor, y: Optional[torch.Tensor] = None, acc_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+        D = z.shape[1]
+        segptr, row_of, _ = self.levels[0]
+        if y is None:
+            y = torch.empty((self.n_rows, D), dtype=torch.float32, device=z.device)
+        if len(self.levels) == 1:
+            return spmm_csr(segptr, row_of, self.col, self.coef, z, self.n_rows, y=y, acc_sum=acc_sum)
+        bufs = self._partials.get(D)
+        if bufs is None:
+            bufs = [torch.empty((lv[0].numel() - 1, D), dtype=torch.float32, device=z.device) for lv in self.levels[:-1]]
+            self._partials[D] = bufs
+        spmm_csr(segptr, row_of, self.col, self.coef, z, self.n_rows, y=y, acc_sum=acc_sum, partial=bufs[0], fixup=False)
+        for li in range(1, len(self.levels)):
+            segptr, row_of, edge_ids = self.levels[li]
+            last = li == len(self.levels) - 1
+            spmm_csr(segptr, row_of, edge_ids, None, bufs[li - 1], self.n_rows, y=y, acc_sum=acc_sum,
+                     partial=None if last else bufs[li], fixup=False)
+        return y
 
 
 def degree_accumulate(dst: torch.Tensor, N: int, deg: torch.Tensor):

@@ -116,18 +116,9 @@ class PreparedGraph:
         counts = torch.bincount(dst, minlength=N)
         rowptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
         rowptr[1:] = torch.cumsum(counts, 0)
-        nseg = torch.clamp((counts + seg_len - 1) // seg_len, min=1)
-        if int(nseg.max()) == 1:
-            self.segptr, self.row_of = rowptr, None
-        else:
-            row_of = torch.repeat_interleave(torch.arange(N, device=dev), nseg)
-            first = torch.cumsum(nseg, 0) - nseg
-            local = torch.arange(row_of.numel(), device=dev) - first[row_of]
-            segptr = torch.empty(row_of.numel() + 1, dtype=torch.int64, device=dev)
-            segptr[:-1] = rowptr[row_of] + local * seg_len
-            segptr[-1] = rowptr[-1]
-            self.segptr, self.row_of = segptr, row_of.to(torch.int32).contiguous()
-        self.partial = None
+        # rows longer than seg_len are split into segments; hub rows are finished by an ordered log-depth tree
+        self.csr = native.SegmentedCSR(rowptr, self.col, self.coef, seg_len=seg_len)
+        self.segptr, self.row_of = self.csr.levels[0][0], self.csr.levels[0][1]
         native.check_oob(dev)
 
 
@@ -183,10 +174,7 @@ class LightGCNConv(_ConvBase):
         return z
 
     def propagate_native(self, x, prep: PreparedGraph, acc_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
-        z = self.hoisted(x, prep)
-        if prep.row_of is not None and (prep.partial is None or prep.partial.shape[1] != z.shape[1]):
-            prep.partial = torch.empty((prep.row_of.numel(), z.shape[1]), dtype=torch.float32, device=x.device)
-        return native.spmm_csr(prep.segptr, prep.row_of, prep.col, prep.coef, z, prep.N, acc_sum=acc_sum, partial=prep.partial)
+        return prep.csr.spmm(self.hoisted(x, prep), acc_sum=acc_sum)
 
     # ---- torch path (training; same maths as the reference, scatter via index_add_) -----------------------
     def forward(self, x, user2item_edge_index, item2user_edge_index, user2item_edge_attr=None, item2user_edge_attr=None):

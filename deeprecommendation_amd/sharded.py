@@ -211,22 +211,7 @@ class PartitionedLightGCN:
             cnt = torch.bincount(dst[keep], minlength=N)
             self.rowptr = torch.zeros(N + 1, dtype=torch.int64, device=dst.device)
             self.rowptr[1:] = torch.cumsum(cnt, 0)
-        self.segptr, self.row_of = self._segments(self.rowptr)
-
-    @staticmethod
-    def _segments(rowptr, seg_len=512):
-        n = rowptr.numel() - 1
-        counts = rowptr[1:] - rowptr[:-1]
-        nseg = torch.clamp((counts + seg_len - 1) // seg_len, min=1)
-        if n == 0 or int(nseg.max()) == 1:
-            return rowptr, None
-        row_of = torch.repeat_interleave(torch.arange(n, device=rowptr.device), nseg)
-        first = torch.cumsum(nseg, 0) - nseg
-        local = torch.arange(row_of.numel(), device=rowptr.device) - first[row_of]
-        segptr = torch.empty(row_of.numel() + 1, dtype=torch.int64, device=rowptr.device)
-        segptr[:-1] = rowptr[row_of] + local * seg_len
-        segptr[-1] = rowptr[-1]
-        return segptr, row_of.to(torch.int32).contiguous()
+        self.csr = native.SegmentedCSR(self.rowptr, self.col, self.coef) if self.ops is None else None
 
     # -- local compute
     def _linear(self, x, lin):
@@ -237,7 +222,7 @@ class PartitionedLightGCN:
     def _spmm(self, z, n_rows, acc=None):
         """y = SpMM(z) over this rank's edges; acc += y fused into the kernel epilogue when given (layer-mean sum)."""
         if self.ops is None:
-            return native.spmm_csr(self.segptr, self.row_of, self.col, self.coef, z, n_rows, acc_sum=acc)
+            return self.csr.spmm(z, acc_sum=acc)
         y = self.ops.spmm(self.rowptr, self.col, self.coef, z, n_rows)
         if acc is not None:
             acc += y

@@ -134,12 +134,17 @@ int ncf_score_fused(int dtype,
  * if dev_sum != NULL:  dev_sum[n, :] += y[n, :]   (layer-sum accumulator for the final mean)
  * z is (Nz, D) with leading dimension ldz; y and sum are (N, D).  D % 4 == 0, D <= 256.
  * coef may be NULL (all ones).  dev_partial: (n_seg, D) floats scratch, required when dev_row_of != NULL.
+ * fixup = 1: rows split over several segments are completed inside this call (one lane group per row walks its
+ *   partials in order — simple, but serial per row).
+ * fixup = 0: such rows are NOT written; their per-segment sums stay in dev_partial[s, :] and the caller finishes them
+ *   with further calls of this same entry (z = dev_partial, col = segment ids, coef = NULL, segments of the partial
+ *   list) until every row is down to one segment — a log-depth ordered tree, used for hub rows with millions of edges.
  * ------------------------------------------------------------------------------------------------ */
 int ncf_spmm_csr(int dtype, const int64_t* dev_segptr, const int32_t* dev_row_of, int64_t n_seg,
                  const int32_t* dev_col, const float* dev_coef,
                  const void* dev_z, int64_t Nz, int64_t ldz, int D,
                  void* dev_y, int64_t ldy, float* dev_sum, int64_t ldsum,
-                 float* dev_partial, ncf_stream_t stream);
+                 float* dev_partial, int fixup, ncf_stream_t stream);
 
 /* deg[n] = number of edges whose destination is n (float, exact below 2^24) — PyG degree(), gnn_ncf.py:48.
  * dev_deg must be zero-filled by the caller; two calls (u2i, i2u) accumulate into the same array, which is
