@@ -14,6 +14,10 @@
 #include "ncf_common.h"
 #include <math.h>
 
+#ifndef ATT_UNROLL
+#define ATT_UNROLL 4
+#endif
+
 namespace ncf {
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -62,32 +66,41 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ pc,
                 pcv = *reinterpret_cast<const f32x4*>(pc + b * ldpc + 4 * c);
                 if (MODE == 0) wv = *reinterpret_cast<const f32x4*>(w1 + 4 * c);
             }
-            for (int64_t e0 = beg; e0 < end; e0 += EPI) {
-                const int64_t e = e0 + eg;
-                float part = 0.f;
-                bool ok = false;
-                if (e < end && active) {
-                    const int64_t i = col[e];
-                    ok = (i >= 0 && i < I);
-                    if (ok) {
-                        const f32x4 r = *reinterpret_cast<const f32x4*>(pr + i * ldpr + 4 * c);
-                        if (MODE == 0) {
-                            part = fmaf(wv[0], fmaxf(pcv[0] + r[0], 0.f), part);
-                            part = fmaf(wv[1], fmaxf(pcv[1] + r[1], 0.f), part);
-                            part = fmaf(wv[2], fmaxf(pcv[2] + r[2], 0.f), part);
-                            part = fmaf(wv[3], fmaxf(pcv[3] + r[3], 0.f), part);
-                        } else {
-                            part = fmaf(pcv[0], r[0], part);
-                            part = fmaf(pcv[1], r[1], part);
-                            part = fmaf(pcv[2], r[2], part);
-                            part = fmaf(pcv[3], r[3], part);
-                        }
+            // ATT_UNROLL entries per lane group are in flight at once: with one dependent (col -> row) load per
+            // iteration the loop ran at one L2/Infinity-Cache round trip per 64/LPA entries (latency-bound, 178 us at
+            // cfg 3); the loads of the unrolled steps are independent and overlap.
+            constexpr int U = ATT_UNROLL;
+            for (int64_t e0 = beg; e0 < end; e0 += (int64_t)EPI * U) {
+                f32x4 r[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t e = e0 + u * EPI + eg;
+                    ok[u] = false;
+                    r[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (e < end && active) {
+                        const int64_t i = col[e];
+                        ok[u] = (i >= 0 && i < I);
+                        if (ok[u]) r[u] = *reinterpret_cast<const f32x4*>(pr + i * ldpr + 4 * c);
                     }
                 }
-                for (int off = 1; off < LPA; off <<= 1) part += __shfl_xor(part, off);
-                if (e < end && c == 0) {
-                    const int64_t i = col[e];
-                    wts[e] = (i >= 0 && i < I) ? part + (MODE == 0 ? b1 : 0.f) : -INFINITY;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t e = e0 + u * EPI + eg;
+                    float part = 0.f;
+                    if (MODE == 0) {
+                        part = fmaf(wv[0], fmaxf(pcv[0] + r[u][0], 0.f), part);
+                        part = fmaf(wv[1], fmaxf(pcv[1] + r[u][1], 0.f), part);
+                        part = fmaf(wv[2], fmaxf(pcv[2] + r[u][2], 0.f), part);
+                        part = fmaf(wv[3], fmaxf(pcv[3] + r[u][3], 0.f), part);
+                    } else {
+                        part = fmaf(pcv[0], r[u][0], part);
+                        part = fmaf(pcv[1], r[u][1], part);
+                        part = fmaf(pcv[2], r[u][2], part);
+                        part = fmaf(pcv[3], r[u][3], part);
+                    }
+                    for (int off = 1; off < LPA; off <<= 1) part += __shfl_xor(part, off);
+                    if (e < end && c == 0) wts[e] = ok[u] ? part + (MODE == 0 ? b1 : 0.f) : -INFINITY;
                 }
             }
         } else {
@@ -135,18 +148,29 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ pc,
         const int c = lane % LPF, eg = lane / LPF, EPI = 64 / LPF;
         const bool active = c < chunks;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int64_t e0 = beg; e0 < end; e0 += EPI) {
-            const int64_t e = e0 + eg;
-            if (e < end && active) {
-                const int64_t i = col[e];
-                if (i >= 0 && i < I) {
-                    const float a = wts[e] * val[e];  // attended_user_matrix entry (:212)
-                    const f32x4 f = *reinterpret_cast<const f32x4*>(feat + i * ldfeat + 4 * c);
-                    acc[0] = fmaf(a, f[0], acc[0]);
-                    acc[1] = fmaf(a, f[1], acc[1]);
-                    acc[2] = fmaf(a, f[2], acc[2]);
-                    acc[3] = fmaf(a, f[3], acc[3]);
+        constexpr int U = ATT_UNROLL;
+        for (int64_t e0 = beg; e0 < end; e0 += (int64_t)EPI * U) {
+            f32x4 f[U];
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t e = e0 + u * EPI + eg;
+                f[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                av[u] = 0.f;
+                if (e < end && active) {
+                    const int64_t i = col[e];
+                    if (i >= 0 && i < I) {
+                        av[u] = wts[e] * val[e];  // attended_user_matrix entry (:212)
+                        f[u] = *reinterpret_cast<const f32x4*>(feat + i * ldfeat + 4 * c);
+                    }
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[0] = fmaf(av[u], f[u][0], acc[0]);
+                acc[1] = fmaf(av[u], f[u][1], acc[1]);
+                acc[2] = fmaf(av[u], f[u][2], acc[2]);
+                acc[3] = fmaf(av[u], f[u][3], acc[3]);
             }
         }
         for (int off = LPF; off < 64; off <<= 1) {
