@@ -224,6 +224,142 @@ __global__ __launch_bounds__(NCF_WG_WAVES * 64, NCF_MIN_WAVES) void score_fused_
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Folded first layer (opt-in, inference-time weight folding): with frozen weights
+//     relu(W1 . cat(a, b) + b1) = relu(PA[ia] + PB[ib]),   PA = TA . W1[:, :EA]^T + b1,   PB = TB . W1[:, EA:]^T
+// so layer 1 needs no matrix work at all: the "embedding" rows become N1-wide pre-activations (4x the table bytes at
+// E = 64, N1 = 256) and the kernel is  gather 2 x N1 floats -> add -> ReLU -> layer 2 (MFMA) -> 1-wide layer.
+// Lane (m, h) loads the 16-byte chunk (8kb + 2g + h) of pair m's two rows DIRECTLY in accumulator-row order
+// (neuron 32kb + 8g + 4h + j), i.e. straight into the B operand of layer 2's k-step 4kb + g.
+// Layer 2's packed weights (N1*N2 floats = 128 KB at 256x128) live in LDS for the whole workgroup (8 waves, 256
+// pairs): they are read with ds_read_b128 on lgkmcnt, so vmcnt tracks ONLY the HBM row gathers and those can be
+// prefetched several k-blocks ahead without the in-order vmcnt making every weight wait queue behind an HBM miss.
+// Bound: fp32 MFMA on layer 2 (2*N1*N2 + 2*N2 FLOP/pair = 65 792 at 256x128) vs HBM 2*N1*4 + 20 B/pair = 2068 B.
+#ifndef NCF_FOLD_PF
+#define NCF_FOLD_PF 2   // accumulator tiles (k-blocks of 32 neurons) of row data requested ahead; measured 2 -> 45.6 us, 3 -> 47.5, 5 -> 55.3, 8 (all up front) -> 69.3
+#endif
+#ifndef NCF_FOLD_ABLATE
+#define NCF_FOLD_ABLATE 0   // diagnostics: 1 = no row gathers in the loop (constant data), 2 = weights from registers only
+#endif
+
+struct FoldArgs {
+    const float* PA; int64_t rowsA; int64_t ldA;
+    const float* PB; int64_t rowsB; int64_t ldB;
+    const int64_t* idxA; const int64_t* idxB;
+    int64_t B;
+    const float* Wp2; const float* b2; const float* wl; const float* bl;
+    float* out; int32_t* oob;
+};
+
+template <int N1, int N2>
+__global__ __launch_bounds__(512, 2) void score_folded_f32_kernel(FoldArgs a) {
+    constexpr int NT1 = N1 / 32, NT2 = N2 / 32, Q2 = N1 / 8;
+    constexpr int PF = NCF_FOLD_PF < NT1 ? NCF_FOLD_PF : NT1;
+    constexpr int RING = PF + 1;
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[Q2 * NT2 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+    const int64_t p = tile * 32 + m;
+    const int64_t pc = p < a.B ? p : a.B - 1;
+
+    const int64_t ia = a.idxA ? a.idxA[pc] : pc;
+    const int64_t ib = a.idxB ? a.idxB[pc] : pc;
+    const bool okA = (ia >= 0) & (ia < a.rowsA), okB = (ib >= 0) & (ib < a.rowsB);
+    if (!(okA & okB) && a.oob && p < a.B) *a.oob = 1;
+    const float* rowA = a.PA + (okA ? ia : 0) * a.ldA + 4 * h;
+    const float* rowB = a.PB + (okB ? ib : 0) * a.ldB + 4 * h;
+    const float zA = okA ? 1.f : 0.f, zB = okB ? 1.f : 0.f;
+
+    // row-data ring: tile kb = chunks g = 0..3 at row + 32kb + 8g
+    f32x4 pa[RING][4], pb[RING][4];
+#pragma unroll
+    for (int t = 0; t < PF; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            pa[t][g] = ldg4(rowA + 32 * t + 8 * g);
+            pb[t][g] = ldg4(rowB + 32 * t + 8 * g);
+        }
+    // layer-2 weights -> LDS once per workgroup
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.Wp2);
+        for (int i = threadIdx.x; i < Q2 * NT2 * 64; i += 512) wlds[i] = src[i];
+    }
+    f32x16 acc2[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bb = ldg4(a.b2 + 32 * nt + 8 * g + 4 * h);
+            acc2[nt][4 * g + 0] = bb[0]; acc2[nt][4 * g + 1] = bb[1];
+            acc2[nt][4 * g + 2] = bb[2]; acc2[nt][4 * g + 3] = bb[3];
+        }
+    __syncthreads();
+
+    const f32x4* wq = wlds + lane;  // + (q*NT2 + nt)*64
+    f32x4 w[2][NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) w[0][nt] = wq[nt * 64];
+#pragma unroll
+    for (int kb = 0; kb < NT1; ++kb) {
+        if (kb + PF < NT1 && NCF_FOLD_ABLATE != 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                pa[(kb + PF) % RING][g] = ldg4(rowA + 32 * (kb + PF) + 8 * g);
+                pb[(kb + PF) % RING][g] = ldg4(rowB + 32 * (kb + PF) + 8 * g);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int q = 4 * kb + g, cur = q & 1, nxt = cur ^ 1;
+            const f32x4 s4 = pa[kb % RING][g] * zA + pb[kb % RING][g] * zB;  // bias b1 is folded into PA
+            f32x4 hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[j] = fmaxf(s4[j], 0.f);
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], hv[j], acc2[nt], 0, 0, 0);
+                if (q + 1 < Q2) w[nxt][nt] = (NCF_FOLD_ABLATE == 2) ? w[cur][nt] : wq[((q + 1) * NT2 + nt) * 64];
+            }
+            if (NCF_FOLD_ABLATE != 2) {
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float partial = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ww = ldg4(a.wl + 32 * nt + 8 * g + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) partial = fmaf(ww[j], fmaxf(acc2[nt][4 * g + j], 0.f), partial);
+        }
+    partial += __shfl_xor(partial, 32);
+    if (h == 0 && p < a.B) a.out[p] = partial + a.bl[0];
+}
+
+template <int N1, int N2>
+static void launch_folded(const FoldArgs& a, hipStream_t s) {
+    const int64_t tiles = (a.B + 31) / 32;
+    hipLaunchKernelGGL((score_folded_f32_kernel<N1, N2>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, s, a);
+}
+
+static bool folded_dispatch(int N1, int N2, const FoldArgs* a, hipStream_t s) {
+#define X(n1, n2) \
+    if (N1 == n1 && N2 == n2) { if (a) launch_folded<n1, n2>(*a, s); return true; }
+    X(256, 128) X(128, 64) X(256, 64) X(128, 128)
+#undef X
+    return false;
+}
+
 // Pack W [N][K] row-major into Wp[q][nt][lane][4].
 __global__ void pack_weight_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ Wp) {
     const int64_t total = (int64_t)N * K;
@@ -380,3 +516,29 @@ extern "C" int ncf_score_fused(int dtype, const void* tabA, int64_t rowsA, int64
 #if NCF_STAMP
 extern "C" void ncf_dev_set_debug_buffer(void* p) { ncf::g_dbg = (unsigned long long*)p; }
 #endif
+
+extern "C" int ncf_score_folded_supported(int dtype, int N1, int N2) {
+    return (dtype == NCF_F32 && folded_dispatch(N1, N2, nullptr, nullptr)) ? 1 : 0;
+}
+
+extern "C" int ncf_score_folded(int dtype, const void* PA, int64_t rowsA, int64_t ldA, const void* PB, int64_t rowsB, int64_t ldB,
+                                const int64_t* idxA, const int64_t* idxB, int64_t B, int N1, int N2, const void* packed_tail,
+                                float* out, int32_t* oob, ncf_stream_t stream) {
+    if (dtype != NCF_F32 || !folded_dispatch(N1, N2, nullptr, nullptr))
+        return fail(NCF_EUNSUPPORTED, "ncf_score_folded: no kernel for dtype=%d N1=%d N2=%d", dtype, N1, N2);
+    if (B == 0) return NCF_OK;
+    if (B < 0 || !PA || !PB || !packed_tail || !out) return fail(NCF_EINVAL, "ncf_score_folded: bad argument");
+    if (ldA < N1 || ldB < N1 || ldA % 4 || ldB % 4 || !aligned16(PA) || !aligned16(PB) || !aligned16(packed_tail))
+        return fail(NCF_EINVAL, "ncf_score_folded: tables must be 16-byte aligned with ld %% 4 == 0 and ld >= N1");
+    const int dims[3] = {N1, N2, 1};
+    const BlobLayout L = blob_layout(dims, 2);  // the tail MLP [N1 -> N2 -> 1] packed by ncf_mlp_pack
+    const float* P = (const float*)packed_tail;
+    FoldArgs a;
+    a.PA = (const float*)PA; a.rowsA = rowsA; a.ldA = ldA;
+    a.PB = (const float*)PB; a.rowsB = rowsB; a.ldB = ldB;
+    a.idxA = idxA; a.idxB = idxB; a.B = B;
+    a.Wp2 = P + L.wp1; a.b2 = P + L.b1; a.wl = P + L.wl; a.bl = P + L.bl;
+    a.out = out; a.oob = oob;
+    folded_dispatch(N1, N2, &a, (hipStream_t)stream);
+    return check_launch("ncf_score_folded");
+}

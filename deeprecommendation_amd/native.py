@@ -47,6 +47,9 @@ SIGNATURES = {
     "ncf_scale_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, ctypes.c_float, _c_p, _c_i64, _c_p]),
     "ncf_attn_forward": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
                                   _c_i64, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "ncf_score_folded_supported": (_c_int, [_c_int, _c_int, _c_int]),
+    "ncf_score_folded": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p,
+                                  _c_p, _c_p, _c_p]),
     "ncf_l2_normalize_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p]),
 }
 
@@ -418,4 +421,27 @@ def l2_normalize_rows(x: torch.Tensor) -> torch.Tensor:
     R, E, ld = _rows2d(x, "x")
     out = torch.empty((R, E), dtype=torch.float32, device=x.device)
     _check(lib.ncf_l2_normalize_rows(_ptr(x), ld, R, E, _ptr(out), out.stride(0), _stream(x)))
+    return out
+
+
+def folded_supported(N1: int, N2: int) -> bool:
+    return bool(load_library().ncf_score_folded_supported(NCF_F32, int(N1), int(N2)))
+
+
+def score_folded(PA: torch.Tensor, idxA, PB: torch.Tensor, idxB, packed_tail: PackedMLP, out: Optional[torch.Tensor] = None,
+                 B: Optional[int] = None) -> torch.Tensor:
+    """Folded-first-layer scoring: relu(PA[idxA] + PB[idxB]) -> tail MLP [N1 -> N2 -> 1] (packed_tail)."""
+    lib = load_library()
+    _dev(PA, "PA"), _dev(PB, "PB")
+    rowsA, N1, ldA = _rows2d(PA, "PA")
+    rowsB, N1b, ldB = _rows2d(PB, "PB")
+    if N1 != N1b or packed_tail.dims[0] != N1 or packed_tail.n_layers != 2:
+        raise ValueError("folded tables and tail MLP disagree")
+    idxA, idxB = _idx(idxA), _idx(idxB)
+    if B is None:
+        B = idxA.numel() if idxA is not None else (idxB.numel() if idxB is not None else rowsA)
+    if out is None:
+        out = torch.empty((B, 1), dtype=torch.float32, device=PA.device)
+    _check(lib.ncf_score_folded(NCF_F32, _ptr(PA), rowsA, ldA, _ptr(PB), rowsB, ldB, _ptr(idxA), _ptr(idxB), B, N1,
+                                packed_tail.dims[1], _ptr(packed_tail.blob), _ptr(out), _ptr(_oob_flag(PA.device)), _stream(PA)))
     return out

@@ -19,6 +19,16 @@ class _ScoringMixin:
     """Derived inference tensors shared by BasicNCF / MF / GraphNCF: embedding tables and packed MLP weights."""
 
     scoring_dtype = torch.float32
+    fold_first_layer = False
+
+    def set_fold_first_layer(self, enabled: bool = True):
+        """Opt-in inference-time folding (frozen weights): relu(W1·cat(a, b) + b1) == relu(PA[ia] + PB[ib]) with
+        PA = TA·W1[:, :EA]^T + b1 and PB = TB·W1[:, EA:]^T built once per weight version.  The first MLP layer then
+        costs no matrix work per pair (ncf_score_folded); the tables grow from E to N1 floats per row.  Same function
+        up to fp32 summation order.  Applies to fp32 MLPs with two hidden layers that have a kernel instance."""
+        self.fold_first_layer = bool(enabled)
+        self._native_ver = None
+        return self
 
     def set_scoring_dtype(self, dtype):
         """float32 (default; 1e-5 parity with the reference) or bfloat16 (BASELINE config 5: bf16 tables and MLP
@@ -57,11 +67,37 @@ class _ScoringMixin:
                 cache[key] = None
         return cache[key]
 
+    def _folded(self, tabA, tabB, mlp_name):
+        """(PA, PB, packed tail MLP) for the folded path, cached per weight version and table pair; None if the MLP
+        shape has no folded kernel."""
+        cache = self._refresh()
+        key = ("folded", mlp_name, tabA.data_ptr(), tabB.data_ptr(), tuple(tabA.shape), tuple(tabB.shape))
+        if key not in cache:
+            lins = mlp_linears(getattr(self, mlp_name))
+            ok = (len(lins) == 3 and lins[2].out_features == 1 and lins[0].in_features == tabA.shape[1] + tabB.shape[1]
+                  and native.folded_supported(lins[0].out_features, lins[1].out_features))
+            if not ok:
+                cache[key] = None
+            else:
+                EA = tabA.shape[1]
+                w1 = lins[0].weight.detach()
+                PA = native.linear(tabA, w1[:, :EA].contiguous(), lins[0].bias.detach())       # b1 folded into PA
+                PB = native.linear(tabB, w1[:, EA:].contiguous(), None)
+                tail = native.PackedMLP([lins[1].weight, lins[2].weight], [lins[1].bias, lins[2].bias])
+                cache[key] = (PA, PB, tail, tabA, tabB)  # keep the source tables alive: the key holds their addresses
+        hit = cache[key]
+        return None if hit is None else hit[:3]
+
     def _score(self, tabA, idxA, tabB, idxB, mlp_name="MLP"):
         """gather(A) ‖ gather(B) -> MLP -> (B,1): fused kernel when the shape has an instance, else K1 + K2."""
-        packed = self._packed_mlp(mlp_name)
         EA = tabA.shape[1]
         EB = 0 if tabB is None else tabB.shape[1]
+        if self.fold_first_layer and tabB is not None and tabA.dtype == torch.float32:
+            folded = self._folded(tabA, tabB, mlp_name)
+            if folded is not None:
+                PA, PB, tail = folded
+                return native.score_folded(PA, idxA, PB, idxB, tail)
+        packed = self._packed_mlp(mlp_name)
         if packed is not None and tabA.dtype == packed.dtype and packed.supports(EA, EB):
             return native.score_fused(tabA, idxA, tabB, idxB, packed)
         if tabA.dtype != torch.float32:

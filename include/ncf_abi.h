@@ -119,6 +119,21 @@ int ncf_score_fused(int dtype,
                     int n_layers, const int* dims, const void* dev_packed,
                     float* dev_out, int32_t* dev_oob_flag, ncf_stream_t stream);
 
+/* Opt-in inference-time folding of the first MLP layer into the tables (frozen weights):
+ *   relu(W1 . cat(a, b) + b1) == relu(PA[ia] + PB[ib])  with  PA = TA . W1[:, :EA]^T + b1  (rowsA, N1)  and
+ *   PB = TB . W1[:, EA:]^T  (rowsB, N1), both built once by the caller (ncf_mlp_forward with n_layers = 1).
+ * out[p] = tail( relu(PA[idxA[p]] + PB[idxB[p]]) ),  tail = the remaining MLP [N1 -> N2 -> 1] packed by
+ * ncf_mlp_pack(dims = {N1, N2, 1}).  Same function as ncf_score_fused up to fp32 summation order; layer 1 costs no
+ * matrix work, the gathered rows are N1 wide (4x the bytes at E = 64, N1 = 256).  Replaces basic_ncf.py:38-41 /
+ * gnn_ncf.py:354-362 like ncf_score_fused.  NCF_EUNSUPPORTED when (N1, N2) has no instance. */
+int ncf_score_folded_supported(int dtype, int N1, int N2);
+int ncf_score_folded(int dtype,
+                     const void* dev_PA, int64_t rowsA, int64_t ldPA,
+                     const void* dev_PB, int64_t rowsB, int64_t ldPB,
+                     const int64_t* dev_idxA, const int64_t* dev_idxB,
+                     int64_t B, int N1, int N2, const void* dev_packed_tail,
+                     float* dev_out, int32_t* dev_oob_flag, ncf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K4/K5  LightGCN propagation as CSR-by-destination SpMM with a wavefront segmented reduction
  * Replaces: PyG MessagePassing.propagate(aggr='add') + message() — models/gnn_ncf.py:52-70,74-94

@@ -316,3 +316,47 @@ def test_score_fused_out_of_range_rows_read_as_zeros(native, gpu):
         assert_close(out, ref, rtol=tol)
         with pytest.raises(IndexError):
             native.check_oob(gpu)
+
+
+# ----------------------------------------------------------------------------- folded first layer (opt-in)
+@pytest.mark.parametrize("E,hidden", [(64, [256, 128]), (32, [256, 128]), (64, [128, 64]), (16, [256, 64]), (64, [128, 128])])
+@pytest.mark.parametrize("B", [1, 255, 256, 257, 2000])
+def test_score_folded_vs_oracle(gpu, E, hidden, B):
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    torch.manual_seed(E + hidden[0])
+    U, I = 3000, 700
+    m = BasicNCF(item_dim=I, user_dim=U, item_emb=E, user_emb=E, mlp_dense_layers=hidden).eval()
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(B)
+    u = torch.randint(0, U, (B,), generator=g)
+    i = torch.randint(0, I, (B,), generator=g)
+    ref = O.basic_ncf_forward_indexed(state, u, i)
+    m.to(gpu)
+    with torch.no_grad():
+        plain = m(u.to(gpu), i.to(gpu))
+        m.set_fold_first_layer(True)
+        out = m(u.to(gpu), i.to(gpu))
+    assert any(k[0] == "folded" and v is not None for k, v in m._native_cache.items() if isinstance(k, tuple))
+    assert_close(out, ref)
+    assert_close(plain, ref)
+
+
+def test_score_folded_out_of_range(native, gpu):
+    g = torch.Generator().manual_seed(0)
+    PA = torch.randn(100, 256, generator=g)
+    PB = torch.randn(50, 256, generator=g)
+    w2 = torch.randn(128, 256, generator=g) / 16
+    b2 = torch.randn(128, generator=g) * 0.1
+    w3 = torch.randn(1, 128, generator=g) / 11
+    b3 = torch.randn(1, generator=g)
+    tail = native.PackedMLP([w2.to(gpu), w3.to(gpu)], [b2.to(gpu), b3.to(gpu)])
+    ia = torch.tensor([3, 100, 5, -1])
+    ib = torch.tensor([1, 2, 50, 4])
+    out = native.score_folded(PA.to(gpu), ia.to(gpu), PB.to(gpu), ib.to(gpu), tail)
+    xa = PA[ia.clamp(0, 99)] * ((ia >= 0) & (ia < 100)).float()[:, None]
+    xb = PB[ib.clamp(0, 49)] * ((ib >= 0) & (ib < 50)).float()[:, None]
+    h = torch.relu((xa + xb).double())
+    ref = (torch.relu(h @ w2.double().t() + b2.double()) @ w3.double().t() + b3.double()).float()
+    assert_close(out, ref)
+    with pytest.raises(IndexError):
+        native.check_oob(gpu)
