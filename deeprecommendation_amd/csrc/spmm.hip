@@ -171,7 +171,7 @@ extern "C" int ncf_spmm_csr(int dtype, const int64_t* segptr, const int32_t* row
         return fail(NCF_EINVAL, "ncf_spmm_csr: rows must be 16-byte aligned (ld %% 4 == 0)");
     if (row_of && !partial && fixup) return fail(NCF_EINVAL, "ncf_spmm_csr: split rows need a partial buffer");
     if (n_seg == 0) return NCF_OK;
-    if (!col) return fail(NCF_EINVAL, "ncf_spmm_csr: col is null");
+    // col may be null for an edgeless graph (every segment empty): the kernel dereferences it only inside a segment
     hipStream_t s = (hipStream_t)stream;
     const int chunks = D / 4;
     const float* zf = (const float*)z;

@@ -194,6 +194,8 @@ def mlp_forward(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequen
     """act chain: Linear, (ReLU, Linear)* — no activation after the last layer.  Any dims, fp32."""
     lib = load_library()
     _dev(x, "x")
+    if x.dtype != torch.float32:
+        raise TypeError(f"mlp_forward computes in fp32; got activations of dtype {x.dtype}")
     B, K0, ldx = _rows2d(x, "x")
     dims = [K0] + [int(w.shape[0]) for w in weights]
     for i, w in enumerate(weights):
