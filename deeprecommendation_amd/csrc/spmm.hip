@@ -9,6 +9,7 @@
 // segment order.  No float atomics anywhere: the result is bitwise reproducible run to run.
 // The layer-mean accumulator (gnn_ncf.py:351) is fused into the epilogue: sum[row] += y[row].
 #include "ncf_common.h"
+#include <math.h>
 
 namespace ncf {
 
@@ -142,6 +143,41 @@ __global__ void scale_rows_kernel(const float* __restrict__ in, int64_t ldin, in
     }
 }
 
+// LightGAT edge attention (gnn_ncf.py:151-177 with PyG softmax): for destination row r with incoming edges e,
+//   out[e] = (attr ? attr[e] : 1) * exp(s[col[e]] - max_r) / (sum_r exp(s[col[.]] - max_r) + 1e-16)
+// where s[n] = w_j . x[n] is the SOURCE half of AttNet(cat(x_j, x_i)); the destination half w_i . x_i + b is constant
+// inside a softmax group and cancels.  One wave per row, two passes over 4-byte scalars (L2-resident).
+__global__ __launch_bounds__(256) void edge_softmax_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           const float* __restrict__ attr, const float* __restrict__ s,
+                                                           int64_t n_rows, int64_t Ns, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave0; r < n_rows; r += nwaves) {
+        const int64_t beg = rowptr[r], end = rowptr[r + 1];
+        float mx = -INFINITY;
+        for (int64_t e = beg + lane; e < end; e += 64) {
+            const int64_t c = col[e];
+            if (c >= 0 && c < Ns) mx = fmaxf(mx, s[c]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float sm = 0.f;
+        for (int64_t e = beg + lane; e < end; e += 64) {
+            const int64_t c = col[e];
+            if (c >= 0 && c < Ns) sm += expf(s[c] - mx);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sm += __shfl_xor(sm, off);
+        const float den = sm + 1e-16f;
+        for (int64_t e = beg + lane; e < end; e += 64) {
+            const int64_t c = col[e];
+            const float a = (c >= 0 && c < Ns) ? expf(s[c] - mx) / den : 0.f;
+            out[e] = attr ? attr[e] * a : a;  // weight * a_scores * W(x_j), :174 / :176
+        }
+    }
+}
+
 template <int LPR>
 static void launch_spmm(const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col, const float* coef,
                         const float* z, int64_t Nz, int64_t ldz, int chunks, float* y, int64_t ldy, float* sum, int64_t ldsum,
@@ -210,4 +246,15 @@ extern "C" int ncf_scale_rows(const float* in, int64_t ldin, int64_t N, int D, f
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, ldin, N, D, divisor, out, ldout);
     return check_launch("ncf_scale_rows");
+}
+
+extern "C" int ncf_edge_softmax_csr(const int64_t* rowptr, const int32_t* col, const float* attr, const float* s, int64_t n_rows,
+                                    int64_t Ns, float* out, ncf_stream_t stream) {
+    if (n_rows < 0 || Ns < 0) return fail(NCF_EINVAL, "ncf_edge_softmax_csr: bad sizes");
+    if (n_rows == 0) return NCF_OK;
+    if (!rowptr || !s) return fail(NCF_EINVAL, "ncf_edge_softmax_csr: null pointer");
+    int64_t blocks = (n_rows + 3) / 4;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(edge_softmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, attr, s, n_rows, Ns, out);
+    return check_launch("ncf_edge_softmax_csr");
 }

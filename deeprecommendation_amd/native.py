@@ -47,6 +47,7 @@ SIGNATURES = {
     "ncf_scale_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, ctypes.c_float, _c_p, _c_i64, _c_p]),
     "ncf_attn_forward": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
                                   _c_i64, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "ncf_edge_softmax_csr": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_score_folded_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "ncf_score_folded": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p,
                                   _c_p, _c_p, _c_p]),
@@ -351,18 +352,21 @@ class SegmentedCSR:
             self.levels.append((segptr, row_of, edge_ids.to(torch.int32).contiguous()))
         self._partials = {}
 
-    def spmm(self, z: torch.Tensor, y: Optional[torch.Tensor] = None, acc_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def spmm(self, z: torch.Tensor, y: Optional[torch.Tensor] = None, acc_sum: Optional[torch.Tensor] = None,
+             coef: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``coef`` overrides the per-edge coefficients for this call (LightGAT recomputes them every layer)."""
         D = z.shape[1]
+        coef = self.coef if coef is None else coef
         segptr, row_of, _ = self.levels[0]
         if y is None:
             y = torch.empty((self.n_rows, D), dtype=torch.float32, device=z.device)
         if len(self.levels) == 1:
-            return spmm_csr(segptr, row_of, self.col, self.coef, z, self.n_rows, y=y, acc_sum=acc_sum)
+            return spmm_csr(segptr, row_of, self.col, coef, z, self.n_rows, y=y, acc_sum=acc_sum)
         bufs = self._partials.get(D)
         if bufs is None:
             bufs = [torch.empty((lv[0].numel() - 1, D), dtype=torch.float32, device=z.device) for lv in self.levels[:-1]]
             self._partials[D] = bufs
-        spmm_csr(segptr, row_of, self.col, self.coef, z, self.n_rows, y=y, acc_sum=acc_sum, partial=bufs[0], fixup=False)
+        spmm_csr(segptr, row_of, self.col, coef, z, self.n_rows, y=y, acc_sum=acc_sum, partial=bufs[0], fixup=False)
         for li in range(1, len(self.levels)):
             segptr, row_of, edge_ids = self.levels[li]
             last = li == len(self.levels) - 1
@@ -446,4 +450,14 @@ def score_folded(PA: torch.Tensor, idxA, PB: torch.Tensor, idxB, packed_tail: Pa
         out = torch.empty((B, 1), dtype=torch.float32, device=PA.device)
     _check(lib.ncf_score_folded(NCF_F32, _ptr(PA), rowsA, ldA, _ptr(PB), rowsB, ldB, _ptr(idxA), _ptr(idxB), B, N1,
                                 packed_tail.dims[1], _ptr(packed_tail.blob), _ptr(out), _ptr(_oob_flag(PA.device)), _stream(PA)))
+    return out
+
+
+def edge_softmax_csr(rowptr: torch.Tensor, col: torch.Tensor, attr: Optional[torch.Tensor], s: torch.Tensor,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = load_library()
+    _dev(s, "s")
+    if out is None:
+        out = torch.empty(max(col.numel(), 1), dtype=torch.float32, device=s.device)[:col.numel()]
+    _check(lib.ncf_edge_softmax_csr(_ptr(rowptr), _ptr(col), _ptr(attr), _ptr(s), rowptr.numel() - 1, s.numel(), _ptr(out), _stream(s)))
     return out

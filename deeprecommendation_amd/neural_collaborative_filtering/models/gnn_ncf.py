@@ -14,7 +14,7 @@ Node numbering follows the reference: items first, user node id = num_items + ra
 
 Training (module.training / autograd recording) keeps to differentiable torch ops, including the reference's
 train-only edge masking, node dropout and message dropout (gnn_ncf.py:246-296,314-333,369-378).
-LightGATConv is a SURVEY §8(f) "next" row: the torch path implements it, the HIP path raises.
+LightGATConv (a SURVEY §8(f) "next" row) scores on the HIP path too: edge softmax kernel + the same SpMM.
 """
 from typing import Optional
 
@@ -113,9 +113,15 @@ class PreparedGraph:
         order = torch.argsort(dst, stable=True)  # keeps the reference's edge order inside each destination
         self.col = src[order].to(torch.int32).contiguous()
         self.coef = coef[order].contiguous()
+        # raw edge weights in CSR order (LightGAT uses weight * attention, no degree normalisation, :173-176)
+        a1, a2 = graph.user2item_edge_attr, graph.item2user_edge_attr
+        self.attr = None if (a1 is None or a2 is None) else torch.cat([a1, a2])[order].float().contiguous()
+        # per-destination softmax groups must not mix edge types: true for non-hetero and for bipartite hetero graphs
+        self.type_pure = (not hetero) or self.split is not None
         counts = torch.bincount(dst, minlength=N)
         rowptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
         rowptr[1:] = torch.cumsum(counts, 0)
+        self.rowptr = rowptr
         # rows longer than seg_len are split into segments; hub rows are finished by an ordered log-depth tree
         self.csr = native.SegmentedCSR(rowptr, self.col, self.coef, seg_len=seg_len)
         self.segptr, self.row_of = self.csr.levels[0][0], self.csr.levels[0][1]
@@ -209,10 +215,31 @@ def _segment_softmax(scores, index, N):
 
 
 class LightGATConv(_ConvBase):
-    """reference gnn_ncf.py:97-177 (torch path only; the HIP kernel for it is a 'next' row)."""
+    """reference gnn_ncf.py:97-177.  HIP scoring path: the per-edge Linear is hoisted per node like LightGCN; the
+    attention score AttNet(cat(x_j, x_i)) = w_j·x_j + (w_i·x_i + b) only needs its SOURCE half inside the per-destination
+    softmax (the rest is constant in a group), so one GEMV gives s[n] = w_j·x[n], ncf_edge_softmax_csr turns it into the
+    per-edge coefficient weight·alpha, and the aggregation is the same segmented SpMM as LightGCN."""
 
     def __init__(self, in_channels, out_channels, hetero, dropout=0.1, **kwargs):
         super().__init__(in_channels, out_channels, hetero, dropout, attention=True)
+
+    hoisted = LightGCNConv.hoisted
+
+    def propagate_native(self, x, prep: "PreparedGraph", acc_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if not prep.type_pure:
+            raise NotImplementedError("LightGAT on a hetero graph whose destinations mix edge types runs on the torch path only")
+        D = x.shape[1]
+        s = torch.empty((x.shape[0], 1), dtype=torch.float32, device=x.device)
+        if not self.hetero:
+            native.linear(x, self.AttNet[0].weight.detach()[:, :D].contiguous(), None, out=s)
+        else:
+            I = prep.split  # items are the sources of item->user edges, users of user->item edges
+            if I > 0:
+                native.linear(x[:I], self.item2user_AttNet[0].weight.detach()[:, :D].contiguous(), None, out=s[:I])
+            if x.shape[0] > I:
+                native.linear(x[I:], self.user2item_AttNet[0].weight.detach()[:, :D].contiguous(), None, out=s[I:])
+        coef = native.edge_softmax_csr(prep.rowptr, prep.col, prep.attr, s.view(-1))
+        return prep.csr.spmm(self.hoisted(x, prep), acc_sum=acc_sum, coef=coef)
 
     def forward(self, x, user2item_edge_index, item2user_edge_index, user2item_edge_attr=None, item2user_edge_attr=None):
         N = x.size(0)
@@ -295,8 +322,6 @@ class GraphNCF(_ScoringMixin, GNN_NCF):
         key = ("combined", id(graph))
         if key in cache:
             return cache[key][1]
-        if self.convType != 'LightGCN':
-            raise NotImplementedError("LightGAT scoring on the HIP path is not built yet (SURVEY §8f next row)")
         pk = ("prep", self.hetero)
         if pk not in graph._prepared:
             graph._prepared[pk] = PreparedGraph(graph, self.hetero)

@@ -170,6 +170,14 @@ int ncf_degree_accumulate(const int64_t* dev_dst, int64_t E, int64_t N, float* d
  * (gnn_ncf.py:49-50,54,58,66 and the product order of :91 / :93). */
 int ncf_edge_coef(const int64_t* dev_src, const int64_t* dev_dst, const float* dev_attr,
                   const float* dev_deg, int64_t E, int64_t N, float* dev_coef, ncf_stream_t stream);
+/* LightGAT edge attention over a CSR-by-destination graph (models/gnn_ncf.py:151-177; PyG softmax(src, index) =
+ * exp(src - max_group) / (sum_group + 1e-16)):
+ *   dev_out[e] = (attr ? attr[e] : 1) * softmax over the edges of e's destination row of s[col[.]]
+ * s[n] = w_j . x[n] is the source half of AttNet(cat(x_j, x_i)) (the destination half + bias is constant inside a
+ * group and cancels in the softmax).  The result is the per-edge coefficient for ncf_spmm_csr. */
+int ncf_edge_softmax_csr(const int64_t* dev_rowptr, const int32_t* dev_col, const float* dev_attr, const float* dev_s,
+                         int64_t n_rows, int64_t Ns, float* dev_out, ncf_stream_t stream);
+
 /* out[n, :] = in[n, :] / divisor  (the division of torch.mean over the L+1 stacked layers, gnn_ncf.py:351). */
 int ncf_scale_rows(const float* dev_in, int64_t ldin, int64_t N, int D, float divisor,
                    float* dev_out, int64_t ldout, ncf_stream_t stream);

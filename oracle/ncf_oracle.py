@@ -228,11 +228,46 @@ def lightgcn_conv(x: torch.Tensor, conv_state: State, hetero: bool,
                                                   conv_state["W.0.weight"], conv_state["W.0.bias"]), N)  # :69
 
 
+def pyg_softmax(src: torch.Tensor, index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """torch_geometric.utils.softmax (PyG 2.0.4): exp(src - max_group) / (sum_group + 1e-16), groups by ``index``."""
+    mx = torch.full((num_nodes, src.shape[1]), -float("inf"), dtype=src.dtype)
+    mx = mx.scatter_reduce(0, index.view(-1, 1).expand_as(src), src, reduce="amax", include_self=True)
+    out = (src - mx[index]).exp()
+    den = torch.zeros((num_nodes, src.shape[1]), dtype=src.dtype).index_add_(0, index, out)
+    return out / (den[index] + 1e-16)
+
+
+def lightgat_conv(x: torch.Tensor, conv_state: State, hetero: bool,
+                  user2item_edge_index: torch.Tensor, item2user_edge_index: torch.Tensor,
+                  user2item_edge_attr: Optional[torch.Tensor] = None,
+                  item2user_edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """models/gnn_ncf.py:128-177 in eval mode, per-edge formulation as the reference does (PARITY UNPINNED: PyG absent)."""
+    N = x.size(0)
+
+    def prop(ei, attr, pre):
+        x_j, x_i = x[ei[0]], x[ei[1]]
+        a = F.linear(torch.cat([x_j, x_i], dim=1), conv_state[f"{pre}AttNet.0.weight"], conv_state[f"{pre}AttNet.0.bias"])  # :158-167
+        a = pyg_softmax(a, ei[1], N)  # :171
+        wname = pre + "W" if pre else "W"
+        wx = F.linear(x_j, conv_state[f"{wname}.0.weight"], conv_state[f"{wname}.0.bias"])
+        msg = attr.view(-1, 1) * a * wx if attr is not None else a * wx  # :173-176
+        return pyg_propagate_add(ei, msg, N)
+
+    if hetero:
+        return (prop(user2item_edge_index, user2item_edge_attr, "user2item_")
+                + prop(item2user_edge_index, item2user_edge_attr, "item2user_"))  # :132-138
+    ei = torch.cat([user2item_edge_index, item2user_edge_index], dim=1)
+    attr = None
+    if user2item_edge_attr is not None and item2user_edge_attr is not None:
+        attr = torch.cat([user2item_edge_attr, item2user_edge_attr], dim=0)
+    return prop(ei, attr, "")
+
+
 def graph_ncf_forward(state: State, hetero: bool, num_gnn_layers: int, concat: bool, use_dot_product: bool,
                       item_features: torch.Tensor, user_features: torch.Tensor,
                       user2item_edge_index: torch.Tensor, item2user_edge_index: torch.Tensor,
                       user2item_edge_attr: Optional[torch.Tensor], item2user_edge_attr: Optional[torch.Tensor],
-                      userIds: torch.Tensor, itemIds: torch.Tensor) -> torch.Tensor:
+                      userIds: torch.Tensor, itemIds: torch.Tensor, convType: str = "LightGCN") -> torch.Tensor:
     """models/gnn_ncf.py:298-367 with ``self.training == False`` (no masking / dropout, :314-333 skipped).
 
     The conv weights are shared by every layer (:227) — state keys are ``gnn_convs.0.*`` (the ModuleList
@@ -244,8 +279,9 @@ def graph_ncf_forward(state: State, hetero: bool, num_gnn_layers: int, concat: b
     conv_state = {k[len("gnn_convs.0."):]: v for k, v in state.items() if k.startswith("gnn_convs.0.")}
     hs = [graph_emb]
     for _ in range(num_gnn_layers):  # :337
-        graph_emb = lightgcn_conv(graph_emb, conv_state, hetero, user2item_edge_index, item2user_edge_index,
-                                  user2item_edge_attr, item2user_edge_attr)
+        conv = lightgcn_conv if convType == "LightGCN" else lightgat_conv
+        graph_emb = conv(graph_emb, conv_state, hetero, user2item_edge_index, item2user_edge_index,
+                         user2item_edge_attr, item2user_edge_attr)
         hs.append(graph_emb)
     if concat:
         combined = torch.cat(hs, dim=1)  # :349
