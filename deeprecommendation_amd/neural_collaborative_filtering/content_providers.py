@@ -1,64 +1,65 @@
-"""Plugin surface of the reference (neural_collaborative_filtering/content_providers.py:4-62): the three abstract
-provider classes a user extends.  Same method names and meanings; no PyG import (``get_graph`` returns a
-``GraphData``, which carries the attributes the reference's PyG ``Data`` object does)."""
+"""Plugin surface of the scoring path: what a user of the framework implements to feed their own content to the models.
+
+Three provider kinds exist, one per model family (the names and method signatures are the contract the datasets and
+evaluation loop call, identical to the upstream project's so existing provider subclasses keep working):
+
+  ContentProvider          fixed per-user / per-item vectors        -> BasicNCF, MF
+  DynamicContentProvider   user profile built from rated items      -> AttentionNCF
+  GraphContentProvider     user-item interaction graph + node ids   -> GraphNCF
+
+A provider may return *positions* (int64, rank of the id among the sorted unique ids) instead of float rows from
+``get_user_profile`` / ``get_item_profile``; the datasets then take the embedding-table path on the GPU.
+"""
+from abc import ABC, abstractmethod
 
 
-class ContentProvider:
-    """Fixed per-item / per-user input vectors (reference content_providers.py:4-19).  ``get_*_profile`` is called
-    with a tuple of ids per batch and returns something stackable: float rows, or — for the table path — int64
-    positions (rank of the id among the sorted unique ids)."""
+class _CatalogueInfo(ABC):
+    """Sizes every provider reports."""
 
+    @abstractmethod
+    def get_num_items(self) -> int:
+        """Number of distinct items known to the provider."""
+
+    @abstractmethod
+    def get_num_users(self) -> int:
+        """Number of distinct users known to the provider."""
+
+
+class _ItemContent(_CatalogueInfo):
+    @abstractmethod
     def get_item_profile(self, itemID):
-        raise NotImplementedError
+        """Vector(s) for one item id or a tuple of ids (one row per id)."""
 
+    @abstractmethod
+    def get_item_feature_dim(self) -> int:
+        """Width of an item vector (== model ``item_dim``)."""
+
+
+class ContentProvider(_ItemContent):
+    @abstractmethod
     def get_user_profile(self, userID):
-        raise NotImplementedError
-
-    def get_num_items(self):
-        raise NotImplementedError
-
-    def get_num_users(self):
-        raise NotImplementedError
-
-    def get_item_feature_dim(self):
-        raise NotImplementedError
+        """Vector(s) for one user id or a tuple of ids (one row per id)."""
 
 
-class DynamicContentProvider:
-    """User profile built from the user's rated items (reference content_providers.py:22-44)."""
-
-    def get_item_profile(self, itemID):
-        raise NotImplementedError
-
-    def get_num_items(self):
-        raise NotImplementedError
-
-    def get_num_users(self):
-        raise NotImplementedError
-
-    def get_item_feature_dim(self):
-        raise NotImplementedError
-
+class DynamicContentProvider(_ItemContent):
+    @abstractmethod
     def collate_interacted_items(self, batch, for_ranking: bool):
-        """Returns (candidate_ids, rated_ids, candidate_items (B,F), rated_items (I,F), user_matrix (B,I) or a
-        SparseRatings, targets | items2) — the 6-tuple consumed at datasets/dynamic_datasets.py:27,57."""
-        raise NotImplementedError
+        """collate_fn for a batch of (userId, itemId, target | item2Id) samples.  Returns the 6-tuple
+        ``(candidate_ids, rated_ids, candidate_items (B, F), rated_items (I, F), user_matrix, targets_or_items2)``
+        where ``user_matrix`` is the (B, I) matrix of normalised ratings of the batch's users over the union of
+        their rated items (0 = unrated), column order == row order of ``rated_items`` — or its CSR form
+        (``models.attention_ncf.SparseRatings``)."""
 
 
-class GraphContentProvider:
-    """Graph + node ids (reference content_providers.py:47-62)."""
-
-    def get_num_items(self):
-        raise NotImplementedError
-
-    def get_num_users(self):
-        raise NotImplementedError
-
+class GraphContentProvider(_CatalogueInfo):
+    @abstractmethod
     def get_user_nodeID(self, userID) -> int:
-        raise NotImplementedError
+        """Graph node id of a user (users come after all items)."""
 
+    @abstractmethod
     def get_item_nodeID(self, itemID) -> int:
-        raise NotImplementedError
+        """Graph node id of an item."""
 
+    @abstractmethod
     def get_graph(self):
-        raise NotImplementedError
+        """The interaction graph (``models.gnn_ncf.GraphData``)."""

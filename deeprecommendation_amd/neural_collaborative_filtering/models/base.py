@@ -1,43 +1,39 @@
-"""Model contract of the reference (models/base.py:6-42): forward / get_model_parameters / save_model /
-is_dataset_compatible / important_hypeparams, and the ``[state_dict, kwargs]`` checkpoint format."""
-from abc import abstractmethod
+"""What every scoring model of this package exposes to the datasets / training / evaluation loops.
 
+The contract is the upstream project's (forward, get_model_parameters, save_model, is_dataset_compatible,
+important_hypeparams; checkpoints are the two-element list ``[state_dict, kwargs]``) so that models written against it
+and checkpoints saved by it interchange.
+"""
 import torch
 from torch import nn
 
 
-def _dataset_names(dataset_class):
-    return {c.__name__ for c in getattr(dataset_class, "__mro__", ())}
-
-
 class NCF(nn.Module):
-    # names of the dataset classes (reference's or this package's — matched by class name through the MRO so that
-    # the reference's own FixedPointwiseDataset etc. are accepted without importing the reference)
-    compatible_datasets = ()
+    """Base of BasicNCF / MF / AttentionNCF.
 
-    def __init__(self):
-        super().__init__()
+    ``compatible_datasets`` lists dataset class NAMES; compatibility is decided by name along the candidate's MRO, so
+    the upstream project's own dataset classes are accepted without importing that project.
+    """
 
-    @abstractmethod
-    def forward(self, *args):
-        raise NotImplementedError
+    compatible_datasets: tuple = ()
 
-    @abstractmethod
-    def get_model_parameters(self) -> dict:
-        raise NotImplementedError
+    def forward(self, *inputs):  # pragma: no cover - abstract
+        raise NotImplementedError(f"{type(self).__name__}.forward")
 
-    def save_model(self, file):
-        torch.save([self.state_dict(), self.get_model_parameters()], file)  # reference models/base.py:18-19
+    def get_model_parameters(self) -> dict:  # pragma: no cover - abstract
+        raise NotImplementedError(f"{type(self).__name__}.get_model_parameters")
 
-    def is_dataset_compatible(self, dataset_class):
-        return bool(_dataset_names(dataset_class) & set(self.compatible_datasets))
+    def is_dataset_compatible(self, dataset_class) -> bool:
+        names = {klass.__name__ for klass in getattr(dataset_class, "__mro__", ())}
+        return not names.isdisjoint(self.compatible_datasets)
 
     def important_hypeparams(self) -> str:
-        return ''
+        return ""
+
+    def save_model(self, file) -> None:
+        """Checkpoint = [state_dict, constructor kwargs]; ``util.load_model`` reads it back."""
+        torch.save([self.state_dict(), self.get_model_parameters()], file)
 
 
 class GNN_NCF(NCF):
-    @abstractmethod
-    def forward(self, *args, **kwargs):
-        """forward(graph, userIds (B,), itemIds (B,), device, mask_targets=True) -> (B, 1)"""
-        raise NotImplementedError
+    """Base of graph models: ``forward(graph, userIds (B,), itemIds (B,), device, mask_targets=True) -> (B, 1)``."""
