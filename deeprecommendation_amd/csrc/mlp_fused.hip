@@ -346,10 +346,98 @@ __global__ __launch_bounds__(512, 2) void score_folded_f32_kernel(FoldArgs a) {
     if (h == 0 && p < a.B) a.out[p] = partial + a.bl[0];
 }
 
+#ifndef NCF_FOLD_DIRECT
+#define NCF_FOLD_DIRECT 1   // 1: weights streamed per wave from L2 like the fused kernel (no LDS, no barrier); 0: LDS-resident W2
+#endif
+#ifndef NCF_FOLD_XD
+#define NCF_FOLD_XD 4       // k-steps of row data requested ahead in the direct variant
+#endif
+
+// Direct variant: exactly the fused kernel's layer-2 step (next step's weights interleaved behind the MFMAs), with the
+// B operand taken from a ring of gathered pre-activation chunks instead of layer-1 accumulators.  One wave = 32 pairs,
+// 256-thread workgroups, two per CU, no LDS and no barrier.  The two row loads of k-step q + XD are issued after the
+// step's weight loads so the in-order vmcnt wait for the next step's weights never queues behind an HBM miss.
+template <int N1, int N2>
+__global__ __launch_bounds__(256, 2) void score_folded_direct_kernel(FoldArgs a) {
+    constexpr int NT2 = N2 / 32, Q2 = N1 / 8;
+    constexpr int XD = NCF_FOLD_XD;
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 32 >= a.B) return;
+    const int64_t p = tile * 32 + m;
+    const int64_t pc = p < a.B ? p : a.B - 1;
+    const int64_t ia = a.idxA ? a.idxA[pc] : pc;
+    const int64_t ib = a.idxB ? a.idxB[pc] : pc;
+    const bool okA = (ia >= 0) & (ia < a.rowsA), okB = (ib >= 0) & (ib < a.rowsB);
+    if (!(okA & okB) && a.oob) *a.oob = 1;
+    const float* rowA = a.PA + (okA ? ia : 0) * a.ldA + 4 * h;
+    const float* rowB = a.PB + (okB ? ib : 0) * a.ldB + 4 * h;
+    const float zA = okA ? 1.f : 0.f, zB = okB ? 1.f : 0.f;
+
+    f32x16 acc2[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bb = ldg4(a.b2 + 32 * nt + 8 * g + 4 * h);
+            acc2[nt][4 * g + 0] = bb[0]; acc2[nt][4 * g + 1] = bb[1];
+            acc2[nt][4 * g + 2] = bb[2]; acc2[nt][4 * g + 3] = bb[3];
+        }
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp2) + lane;
+    f32x4 w[2][NT2];
+    f32x4 xa[XD], xb[XD];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) w[0][nt] = wp[nt * 64];
+#pragma unroll
+    for (int t = 0; t < XD - 1; ++t)
+        if (t < Q2) { xa[t] = ldg4(rowA + 8 * t); xb[t] = ldg4(rowB + 8 * t); }
+#pragma unroll
+    for (int q = 0; q < Q2; ++q) {
+        const int cur = q & 1, nxt = cur ^ 1;
+        const f32x4 s4 = xa[q % XD] * zA + xb[q % XD] * zB;  // b1 is folded into PA
+        f32x4 hv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hv[j] = fmaxf(s4[j], 0.f);
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], hv[j], acc2[nt], 0, 0, 0);
+            if (q + 1 < Q2) w[nxt][nt] = wp[((q + 1) * NT2 + nt) * 64];
+        }
+        if (q + XD - 1 < Q2) {
+            xa[(q + XD - 1) % XD] = ldg4(rowA + 8 * (q + XD - 1));
+            xb[(q + XD - 1) % XD] = ldg4(rowB + 8 * (q + XD - 1));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float partial = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ww = ldg4(a.wl + 32 * nt + 8 * g + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) partial = fmaf(ww[j], fmaxf(acc2[nt][4 * g + j], 0.f), partial);
+        }
+    partial += __shfl_xor(partial, 32);
+    if (h == 0 && p < a.B) a.out[p] = partial + a.bl[0];
+}
+
 template <int N1, int N2>
 static void launch_folded(const FoldArgs& a, hipStream_t s) {
     const int64_t tiles = (a.B + 31) / 32;
-    hipLaunchKernelGGL((score_folded_f32_kernel<N1, N2>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, s, a);
+    if (NCF_FOLD_DIRECT)
+        hipLaunchKernelGGL((score_folded_direct_kernel<N1, N2>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((score_folded_f32_kernel<N1, N2>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, s, a);
 }
 
 static bool folded_dispatch(int N1, int N2, const FoldArgs* a, hipStream_t s) {
