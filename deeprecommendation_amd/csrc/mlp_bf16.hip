@@ -21,6 +21,9 @@
 #ifndef NCF_BF16_MSTEP
 #define NCF_BF16_MSTEP 4     // 16-wide k-steps per weight slab (= per barrier); measured 2 -> 20.8 us, 4 -> 19.3 us
 #endif
+#ifndef NCF_BF16_WGW
+#define NCF_BF16_WGW 8       // waves per workgroup sharing a weight slab; measured: 8 -> 19.6 us, 4 (two WGs per CU) -> 20.4, 2 -> 24-28
+#endif
 #ifndef NCF_BF16_ABLATE
 #define NCF_BF16_ABLATE 0    // diagnostics: 1 = no gathered-row loads, 2 = no weight slab copies / barriers
 #endif
@@ -64,20 +67,21 @@ __device__ __forceinline__ bf16x8_t pack_relu8(const f32x16& acc, int base) {
 }
 
 template <int K0, int N1, int N2>
-__global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
+__global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(Bf16Args a) {
+    constexpr int WGW = NCF_BF16_WGW;
     constexpr int NT1 = N1 / 32, Q1 = K0 / 16;   // layer 1: Q1 k-steps of 16
     constexpr int NT2 = N2 / 32, Q2 = N1 / 16;   // layer 2
     constexpr int XD = NCF_BF16_X_DEPTH < Q1 ? NCF_BF16_X_DEPTH : Q1;
     constexpr int MS = NCF_BF16_MSTEP;
     constexpr int SLAB1 = MS * NT1 * 1024;       // bytes per macro-step (MS k-steps) of layer 1
     constexpr int SLAB2 = MS * NT2 * 1024;
-    constexpr int PIECES1 = SLAB1 / 1024 / 8;    // 1-KiB pieces per wave per slab
-    constexpr int PIECES2 = (SLAB2 / 1024 + 7) / 8;
+    constexpr int PIECES1 = SLAB1 / 1024 / WGW;  // 1-KiB pieces per wave per slab
+    constexpr int PIECES2 = (SLAB2 / 1024 + WGW - 1) / WGW;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][SLAB1];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
-    const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+    const int64_t tile = (int64_t)blockIdx.x * WGW + wave;
     const int64_t p = tile * 32 + m;
     const int64_t pc = p < a.B ? p : a.B - 1;     // waves past the end still take part in copies and barriers
 
@@ -121,17 +125,27 @@ __global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
         }
     __syncthreads();
 
+    // Slab pipeline (one barrier per slab of MS k-steps).  A fragments of k-step s+1 are read from LDS while k-step
+    // s's MFMAs run (register double buffer wa[2]); the barrier sits BEFORE the slab's last k-step, after that
+    // step's fragments are in registers and after this wave has written its pieces of the NEXT slab, so the last
+    // k-step can already prefetch the next slab's first fragments: no MFMA ever waits on an LDS read issued in the
+    // same step (hipcc's own schedule put `ds_read; s_waitcnt lgkmcnt(0)` in front of every MFMA after a barrier).
+    u32x4 wa[2][NT1];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) wa[0][nt] = *reinterpret_cast<const u32x4*>(&lds[0][nt * 1024 + lane * 16]);
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---------------- layer 1 ----------------
 #pragma unroll
     for (int t = 0; t < Q1 / MS; ++t) {
         const int cur = t & 1;
-        // fetch the next slab (layer 1's next, or layer 2's first) into registers
         u32x4 nxt[PIECES1];
         const bool more1 = t + 1 < Q1 / MS;
-        if (more1 || N2 > 0) {
+        const bool have_next = more1 || N2 > 0;
+        const int npieces = more1 ? PIECES1 : PIECES2;
+        if (have_next) {
             const unsigned char* src = more1 ? reinterpret_cast<const unsigned char*>(a.Wp1) + (size_t)(t + 1) * SLAB1
                                              : reinterpret_cast<const unsigned char*>(a.Wp2);
-            const int npieces = more1 ? PIECES1 : PIECES2;
 #pragma unroll
             for (int i = 0; i < PIECES1; ++i)
                 if (i < npieces) {
@@ -139,44 +153,44 @@ __global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
                     if (more1 || piece * 1024 < SLAB2) nxt[i] = ldg16(src + piece * 1024 + lane * 16);
                 }
         }
-        // A fragments of k-step qq+1 are read from LDS while k-step qq's MFMAs run (register double buffer): hipcc's
-        // own schedule waits lgkmcnt(0) in front of every second MFMA, exposing the LDS latency ~100 times per tile.
-        u32x4 wa[2][NT1];
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) wa[0][nt] = *reinterpret_cast<const u32x4*>(&lds[cur][nt * 1024 + lane * 16]);
 #pragma unroll
         for (int qq = 0; qq < MS; ++qq) {
             const int q = MS * t + qq;
+            if (qq == MS - 1) {
+                if (have_next) {
+#pragma unroll
+                    for (int i = 0; i < PIECES1; ++i)
+                        if (i < npieces) {
+                            const int piece = wave * npieces + i;
+                            if (more1 || piece * 1024 < SLAB2)
+                                *reinterpret_cast<u32x4*>(&lds[cur ^ 1][piece * 1024 + lane * 16]) = nxt[i];
+                        }
+                }
+                __syncthreads();
+            }
             u32x4 xr = x[q % XD];
             if (!(q < qa ? okA : okB)) xr = u32x4{0u, 0u, 0u, 0u};  // out-of-range row reads as zeros
             if (q + XD < Q1 && NCF_BF16_ABLATE != 1) x[q % XD] = ldg16(xsrc(q + XD));
             const bf16x8_t xb = as_bf16x8(xr);
+            // fragments for the following k-step: same slab, or (last k-step) the first k-step of the next slab
+            const bool pf = qq + 1 < MS || have_next;
+            const int pf_nt = (qq + 1 < MS || more1) ? NT1 : NT2;
+            const unsigned char* pf_base = qq + 1 < MS ? &lds[cur][(qq + 1) * NT1 * 1024] : &lds[cur ^ 1][0];
 #pragma unroll
             for (int nt = 0; nt < NT1; ++nt) {
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa[qq & 1][nt]), xb, acc1[nt], 0, 0, 0);
-                if (qq + 1 < MS)
-                    wa[(qq + 1) & 1][nt] = *reinterpret_cast<const u32x4*>(&lds[cur][((qq + 1) * NT1 + nt) * 1024 + lane * 16]);
+                if (pf && nt < pf_nt)
+                    wa[(qq + 1) & 1][nt] = *reinterpret_cast<const u32x4*>(pf_base + nt * 1024 + lane * 16);
             }
-            if (qq + 1 < MS) {
+            if (pf) {
 #pragma unroll
                 for (int nt = 0; nt < NT1; ++nt) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                    if (nt < pf_nt) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more1 || N2 > 0) {
-            const int npieces = more1 ? PIECES1 : PIECES2;
-#pragma unroll
-            for (int i = 0; i < PIECES1; ++i)
-                if (i < npieces) {
-                    const int piece = wave * npieces + i;
-                    if (more1 || piece * 1024 < SLAB2)
-                        *reinterpret_cast<u32x4*>(&lds[cur ^ 1][piece * 1024 + lane * 16]) = nxt[i];
-                }
-        }
-        __syncthreads();
     }
 
     float partial = 0.f;
@@ -212,19 +226,25 @@ __global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
                     if (piece * 1024 < SLAB2) nxt[i] = ldg16(src + piece * 1024 + lane * 16);
                 }
             }
-            u32x4 wa[2][NT2];
-#pragma unroll
-            for (int nt = 0; nt < NT2; ++nt) wa[0][nt] = *reinterpret_cast<const u32x4*>(&lds[cur][nt * 1024 + lane * 16]);
 #pragma unroll
             for (int qq = 0; qq < MS; ++qq) {
                 const int q = MS * t + qq;  // k-step q = 2*kb + s'
+                if (qq == MS - 1 && more) {
+#pragma unroll
+                    for (int i = 0; i < PIECES2; ++i) {
+                        const int piece = wave * PIECES2 + i;
+                        if (piece * 1024 < SLAB2) *reinterpret_cast<u32x4*>(&lds[cur ^ 1][piece * 1024 + lane * 16]) = nxt[i];
+                    }
+                    __syncthreads();
+                }
+                const bool pf = qq + 1 < MS || more;
+                const unsigned char* pf_base = qq + 1 < MS ? &lds[cur][(qq + 1) * NT2 * 1024] : &lds[cur ^ 1][0];
 #pragma unroll
                 for (int nt = 0; nt < NT2; ++nt) {
                     acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa[qq & 1][nt]), hb[q >> 1][q & 1], acc2[nt], 0, 0, 0);
-                    if (qq + 1 < MS)
-                        wa[(qq + 1) & 1][nt] = *reinterpret_cast<const u32x4*>(&lds[cur][((qq + 1) * NT2 + nt) * 1024 + lane * 16]);
+                    if (pf) wa[(qq + 1) & 1][nt] = *reinterpret_cast<const u32x4*>(pf_base + nt * 1024 + lane * 16);
                 }
-                if (qq + 1 < MS) {
+                if (pf) {
 #pragma unroll
                     for (int nt = 0; nt < NT2; ++nt) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -233,14 +253,6 @@ __global__ __launch_bounds__(512, 2) void score_fused_bf16_kernel(Bf16Args a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < PIECES2; ++i) {
-                    const int piece = wave * PIECES2 + i;
-                    if (piece * 1024 < SLAB2) *reinterpret_cast<u32x4*>(&lds[cur ^ 1][piece * 1024 + lane * 16]) = nxt[i];
-                }
-            }
-            __syncthreads();
         }
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt)
@@ -313,7 +325,7 @@ static Bf16Blob bf16_blob(const int* dims, int n_layers) {
 template <int K0, int N1, int N2>
 static void launch_bf16(const Bf16Args& a, hipStream_t s) {
     const int64_t tiles = (a.B + 31) / 32;
-    hipLaunchKernelGGL((score_fused_bf16_kernel<K0, N1, N2>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((score_fused_bf16_kernel<K0, N1, N2>), dim3((unsigned)((tiles + NCF_BF16_WGW - 1) / NCF_BF16_WGW)), dim3(NCF_BF16_WGW * 64), 0, s, a);
 }
 
 #define NCF_BF16_INSTANCES(X) X(256, 256, 128) X(256, 256, 0) X(128, 256, 128) X(128, 256, 0)
