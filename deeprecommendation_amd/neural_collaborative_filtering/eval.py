@@ -10,40 +10,39 @@ from torch.utils.data import DataLoader
 from .datasets.base import PointwiseDataset
 
 
-def _dcg(y_true, y_score, k):
-    """DCG@k with sklearn's tie handling (ties in the scores share the average gain of their tie group)."""
-    n = y_true.shape[0]
-    disc = 1.0 / np.log2(np.arange(n) + 2.0)
-    disc[k:] = 0.0
-    cum = np.cumsum(disc)
-    _, inv, cnt = np.unique(-y_score, return_inverse=True, return_counts=True)
-    gain = np.bincount(inv, weights=y_true, minlength=len(cnt)) / cnt
-    ends = np.cumsum(cnt) - 1
-    dsum = np.diff(np.concatenate(([0.0], cum[ends])))
-    return float(np.dot(gain, dsum))
+def _dcg_per_user(user_idx, n_users, y_true, y_score, k):
+    """DCG@k of every user at once, with sklearn's tie handling (dcg_score(ignore_ties=False)): inside a user, items
+    with equal scores share the average gain of their tie group.  Fully vectorised: one lexsort over all rows."""
+    order = np.lexsort((-y_score, user_idx))                 # by user, then by descending score
+    u, t, sc = user_idx[order], y_true[order], y_score[order]
+    first_of_user = np.r_[True, u[1:] != u[:-1]]
+    start = np.maximum.accumulate(np.where(first_of_user, np.arange(len(u)), 0))
+    rank = np.arange(len(u)) - start                          # 0-based rank inside the user
+    disc = np.where(rank < k, 1.0 / np.log2(rank + 2.0), 0.0)
+    new_group = first_of_user | np.r_[True, sc[1:] != sc[:-1]]
+    gid = np.cumsum(new_group) - 1
+    cnt = np.bincount(gid)
+    gain = np.bincount(gid, weights=t) / cnt                  # mean gain of each tie group
+    dsum = np.bincount(gid, weights=disc)                     # discounts the group's positions collect
+    return np.bincount(u[new_group], weights=gain * dsum, minlength=n_users)
 
 
 def eval_ranking(samples_with_preds, cutoff=10):
     """eval.py:25-75.  ``samples_with_preds``: DataFrame with userId, rating, prediction columns.  Users with a single
-    row (:38) or with ideal DCG == worst DCG (:57) are ignored; returns (mean NDCG, mean adjusted NDCG)."""
+    row (:38) or with ideal DCG == worst DCG (:57) are ignored; returns (mean NDCG, mean adjusted NDCG).
+    The reference loops over users calling sklearn three times each; this computes all users in one pass."""
     users = samples_with_preds['userId'].to_numpy()
     rating = samples_with_preds['rating'].to_numpy(dtype=np.float64)
     pred = samples_with_preds['prediction'].to_numpy(dtype=np.float64)
-    order = np.argsort(users, kind='stable')
-    _, starts = np.unique(users[order], return_index=True)
-    bounds = np.append(starts, len(order))
-    ndcgs, adjs = [], []
-    for a, b in zip(bounds[:-1], bounds[1:]):
-        if b - a <= 1:
-            continue
-        rows = order[a:b]
-        t, p = rating[rows], pred[rows]
-        dcg, ideal, worst = _dcg(t, p, cutoff), _dcg(t, t, cutoff), _dcg(t, 5.0 - t, cutoff)
-        if ideal == worst:
-            continue
-        ndcgs.append(dcg / ideal if ideal != 0 else 0.0)
-        adjs.append((dcg - worst) / (ideal - worst))
-    return float(np.mean(ndcgs)), float(np.mean(adjs))
+    _, uidx, counts = np.unique(users, return_inverse=True, return_counts=True)
+    n = len(counts)
+    dcg = _dcg_per_user(uidx, n, rating, pred, cutoff)
+    ideal = _dcg_per_user(uidx, n, rating, rating, cutoff)
+    worst = _dcg_per_user(uidx, n, rating, 5.0 - rating, cutoff)
+    keep = (counts > 1) & (ideal != worst)
+    ndcg = np.where(ideal[keep] != 0, dcg[keep] / np.where(ideal[keep] != 0, ideal[keep], 1.0), 0.0)
+    adj = (dcg[keep] - worst[keep]) / (ideal[keep] - worst[keep])
+    return float(np.mean(ndcg)), float(np.mean(adj))
 
 
 def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False, device=None, verbose=False):
@@ -62,6 +61,9 @@ def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False,
             if not ranking:
                 total += test_dataset.calculate_loss(out, y.to(device)).item()
             fitted.append(out.detach().cpu().numpy())
+    if device is not None and torch.device(device).type == "cuda":
+        from .. import native
+        native.check_oob(torch.device(device))  # an out-of-range id anywhere in the run raises IndexError here
     pred = np.concatenate(fitted).astype(np.float64).reshape(-1)
     res = {"predictions": pred}
     if not ranking:

@@ -117,3 +117,34 @@ def test_attention_weights_are_a_distribution(gpu):
     out_p, _ = native.attn_forward(native.ATT_MLP, pc[perm].contiguous(), pr, w1, 0.1, rowptr,
                                    col.view(B, nnz)[perm].reshape(-1).contiguous(), val.view(B, nnz)[perm].reshape(-1).contiguous(), feat)
     assert torch.equal(out_p, out[perm])
+
+
+def test_serving_shape_one_user_whole_catalogue(gpu):
+    """The reference web backend's call shape (webapp/backend.py:78-121): candidates = every unseen item of the
+    catalogue, rated_items = the user's rated items only, user_matrix = the same row repeated B times,
+    return_attention_weights=True; top-k by score must agree with the oracle."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
+    torch.manual_seed(21)
+    F, n_items, n_rated, k = 96, 1248, 37, 10
+    m = AttentionNCF(item_dim=F, item_emb=128, user_emb=128, att_dense=128, mlp_dense_layers=[256, 128]).eval()
+    state = {k_: v.clone() for k_, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    feats = (torch.rand(n_items, F, generator=g) < 0.1).float() + torch.rand(n_items, F, generator=g) * 0.05
+    rated_idx = torch.randperm(n_items, generator=g)[:n_rated].sort().values
+    ratings = torch.randint(1, 11, (n_rated,), generator=g).float() * 0.5
+    unseen = torch.ones(n_items, dtype=torch.bool)
+    unseen[rated_idx] = False
+    cand = feats[unseen]
+    rated = feats[rated_idx]
+    row = ratings - (ratings.mean() + 2.5) / 2
+    um = row.unsqueeze(0).repeat(cand.shape[0], 1)
+    ref_out, ref_att = O.attention_ncf_forward(state, cand, rated, um, return_attention_weights=True)
+    m.to(gpu)
+    with torch.no_grad():
+        out, att = m(cand.to(gpu), rated.to(gpu), um.to(gpu), return_attention_weights=True)
+    assert_close(out, ref_out)
+    assert_close(att, ref_att)
+    assert att.shape == (cand.shape[0], n_rated)
+    top_ref = torch.topk(ref_out.view(-1), k).indices
+    top = torch.topk(out.view(-1).cpu(), k).indices
+    assert torch.equal(top, top_ref)
