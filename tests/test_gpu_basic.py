@@ -360,3 +360,23 @@ def test_score_folded_out_of_range(native, gpu):
     assert_close(out, ref)
     with pytest.raises(IndexError):
         native.check_oob(gpu)
+
+
+@pytest.mark.parametrize("E,hidden", [(64, [256, 128]), (32, [256]), (128, [256, 128]), (64, [128, 64])])
+def test_score_fused_bit_exact_vs_kernel_order_c_oracle(native, gpu, E, hidden):
+    """The fp32 MFMA is an exact k-ordered fmaf chain, so the fused kernel must equal — BIT FOR BIT — a plain C
+    restatement of its operation order (oracle/ncf_oracle_c.c, itself held to the reference goldens at 1e-5)."""
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(E + len(hidden))
+    dims = [2 * E] + hidden + [1]
+    B = 3000
+    ta = torch.randn(700, E, generator=g) * 0.5
+    tb = torch.randn(300, E, generator=g) * 0.5
+    ia = torch.randint(0, 700, (B,), generator=g)
+    ib = torch.randint(0, 300, (B,), generator=g)
+    ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(len(dims) - 1)]
+    packed = native.PackedMLP([w.to(gpu) for w in ws], [b.to(gpu) for b in bs])
+    out = native.score_fused(ta.to(gpu), ia.to(gpu), tb.to(gpu), ib.to(gpu), packed)
+    ref = c_oracle.score_fused_f32(ta, tb, ia, ib, ws, bs)
+    assert torch.equal(out.cpu(), ref), f"max abs diff {(out.cpu() - ref).abs().max().item():.3e}"

@@ -137,3 +137,25 @@ def test_lightgcn_edge_list_vs_dense_adjacency(hetero, binary):
     y = O.lightgcn_conv(x, cs, hetero, u2i, i2u, a1, a2)
     yd = O.lightgcn_conv_dense(x, cs, hetero, u2i, i2u, a1, a2)
     assert torch.allclose(y.double(), yd, rtol=1e-5, atol=1e-6)
+
+
+def test_c_kernel_order_oracle_agrees_with_reference_level_oracle():
+    """oracle/ncf_oracle_c.c restates the fused kernel's fp32 operation ORDER; it must still be the same function as the
+    reference-level oracle (to fp32 rounding) and reproduce the reference's golden outputs to 1e-5."""
+    from oracle import c_oracle
+    state, a, kw = load_golden("g1_basic_onehot_e32")  # E = 32, MLP [256, 128]: tileable like the kernel
+    tu = O.embedding_table(state["user_embeddings.0.weight"], state["user_embeddings.0.bias"])
+    ti = O.embedding_table(state["item_embeddings.0.weight"], state["item_embeddings.0.bias"])
+    layers = O.mlp_weights(state)
+    out = c_oracle.score_fused_f32(tu, ti, torch.as_tensor(a["user_pos"]), torch.as_tensor(a["item_pos"]),
+                                   [w for w, _ in layers], [b for _, b in layers])
+    ref = torch.from_numpy(a["out"])
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    state, a, kw = load_golden("cfg1_basic_ml1m")       # E = 32, MLP [256]
+    tu = O.embedding_table(state["user_embeddings.0.weight"], state["user_embeddings.0.bias"])
+    ti = O.embedding_table(state["item_embeddings.0.weight"], state["item_embeddings.0.bias"])
+    layers = O.mlp_weights(state)
+    sub = slice(0, 4096)
+    out = c_oracle.score_fused_f32(tu, ti, torch.as_tensor(a["user_pos"][sub].astype(np.int64)),
+                                   torch.as_tensor(a["item_pos"][sub].astype(np.int64)), [w for w, _ in layers], [b for _, b in layers])
+    assert torch.allclose(out, torch.from_numpy(a["out"][sub]), rtol=1e-5, atol=1e-6)
