@@ -15,6 +15,9 @@
 #ifndef NCF_G_NT_LOAD
 #define NCF_G_NT_LOAD 0       // 1: non-temporal loads for the table rows
 #endif
+#ifndef NCF_G_NT_IDX
+#define NCF_G_NT_IDX 0        // 1: non-temporal loads for the (read-once) index arrays
+#endif
 #ifndef NCF_G_THREADS
 #define NCF_G_THREADS 256     // workgroup size of the vector gather kernel
 #endif
@@ -42,8 +45,8 @@ __global__ __launch_bounds__(NCF_G_THREADS) void gather_concat_vec16(
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t p = base + u * PPW + lane / LPP;
             if (p >= B) continue;
-            int64_t ia = idxA ? idxA[p] : p;
-            int64_t ib = chunksB ? (idxB ? idxB[p] : p) : 0;
+            int64_t ia = idxA ? (NCF_G_NT_IDX ? __builtin_nontemporal_load(idxA + p) : idxA[p]) : p;
+            int64_t ib = chunksB ? (idxB ? (NCF_G_NT_IDX ? __builtin_nontemporal_load(idxB + p) : idxB[p]) : p) : 0;
             const bool okA = (ia >= 0) & (ia < rowsA);
             const bool okB = chunksB == 0 || ((ib >= 0) & (ib < rowsB));
             if (!(okA && okB) && oob && sub == 0) *oob = 1;

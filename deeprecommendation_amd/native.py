@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 
@@ -308,7 +308,6 @@ class SegmentedCSR:
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, coef: Optional[torch.Tensor], seg_len: int = 512, fan: int = 64):
         self.n_rows = rowptr.numel() - 1
         self.col, self.coef = col, coef
-        dev = rowptr.device
         counts = rowptr[1:] - rowptr[:-1]
         self._build_tree(rowptr, counts, seg_len, fan)
 

@@ -2,7 +2,6 @@
 ``use_collate()`` hook, a static ``do_forward(model, batch, device, ...)`` and ``calculate_loss``.
 Ranking datasets (BPR loss + negative sampling, base.py:45-99) belong to training and are not mirrored."""
 import pandas as pd
-import torch
 from torch import nn
 from torch.utils.data import Dataset
 

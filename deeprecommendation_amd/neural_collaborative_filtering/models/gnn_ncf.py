@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import native
-from ..util import build_MLP_layers, params_version, require_gpu, use_native
+from ..util import build_MLP_layers, require_gpu, use_native
 from .base import GNN_NCF
 from .basic_ncf import _ScoringMixin
 

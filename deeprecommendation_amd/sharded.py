@@ -144,7 +144,6 @@ class PartitionedLightGCN:
     """
 
     def __init__(self, model, graph, mode="dst", group=None, local_ops=None):
-        from .neural_collaborative_filtering.models.gnn_ncf import PreparedGraph  # noqa: F401 (documented dependency)
         if mode not in ("dst", "edge"):
             raise ValueError("mode must be 'dst' or 'edge'")
         self.model, self.mode, self.group = model, mode, group

@@ -25,7 +25,6 @@ Pinning (tests/test_oracle_golden.py):
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np

@@ -1,7 +1,6 @@
 """GPU parity tests for K3 (AttentionNCF item-item attention) against reference goldens and the CPU oracle."""
 import os
 
-import numpy as np
 import pytest
 import torch
 

@@ -3,8 +3,6 @@ they must reduce to the single-GPU product path."""
 import pytest
 import torch
 
-from oracle import ncf_oracle as O
-from test_gpu_basic import assert_close
 
 pytestmark = pytest.mark.gpu
 
