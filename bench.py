@@ -152,7 +152,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("NCF_BENCH_FORCE_DIST") == "1":  # FORCE_DIST: exercise the RCCL init/barrier path at world size 1
         import torch.distributed as dist
         backend = os.environ.get("NCF_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for rehearsals
         if backend == "nccl":

@@ -24,11 +24,21 @@
 #ifndef NCF_BF16_WGW
 #define NCF_BF16_WGW 8       // waves per workgroup sharing a weight slab; measured: 8 -> 19.6 us, 4 (two WGs per CU) -> 20.4, 2 -> 24-28
 #endif
+#ifndef NCF_BF16_STAMP
+#define NCF_BF16_STAMP 0     // diagnostic builds only (tools/ab_bf16.py): phase stamps written behind the outputs
+#endif
 #ifndef NCF_BF16_ABLATE
 #define NCF_BF16_ABLATE 0    // diagnostics: 1 = no gathered-row loads, 2 = no weight slab copies / barriers
 #endif
 
 namespace ncf {
+
+#if NCF_BF16_STAMP
+static unsigned long long* g_bf16_dbg = nullptr;
+#define BF16_STAMP(i) do { if (a.dbg && lane == 0) { a.dbg[tile * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define BF16_STAMP(i) do { } while (0)
+#endif
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -43,6 +53,9 @@ struct Bf16Args {
     const unsigned short* Wp2; const float* b2;
     const float* wl; const float* bl;
     float* out; int32_t* oob;
+#if NCF_BF16_STAMP
+    unsigned long long* dbg;
+#endif
 };
 
 __device__ __forceinline__ u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -84,6 +97,7 @@ __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(
     const int64_t tile = (int64_t)blockIdx.x * WGW + wave;
     const int64_t p = tile * 32 + m;
     const int64_t pc = p < a.B ? p : a.B - 1;     // waves past the end still take part in copies and barriers
+    BF16_STAMP(0);
 
     const int64_t ia = a.idxA ? a.idxA[pc] : pc;
     const bool okA = (ia >= 0) & (ia < a.rowsA);
@@ -124,6 +138,7 @@ __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(
             acc1[nt][4 * g + 2] = bb[2]; acc1[nt][4 * g + 3] = bb[3];
         }
     __syncthreads();
+    BF16_STAMP(1);
 
     // Slab pipeline (one barrier per slab of MS k-steps).  A fragments of k-step s+1 are read from LDS while k-step
     // s's MFMAs run (register double buffer wa[2]); the barrier sits BEFORE the slab's last k-step, after that
@@ -193,6 +208,7 @@ __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(
         }
     }
 
+    BF16_STAMP(2);
     float partial = 0.f;
     if constexpr (N2 > 0) {
         // activations of layer 1 -> bf16 B fragments (frees the fp32 accumulators)
@@ -211,6 +227,7 @@ __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(
                 acc2[nt][4 * g + 0] = bb[0]; acc2[nt][4 * g + 1] = bb[1];
                 acc2[nt][4 * g + 2] = bb[2]; acc2[nt][4 * g + 3] = bb[3];
             }
+        BF16_STAMP(3);
         constexpr int T0 = (Q1 / MS) & 1;  // LDS buffer holding layer 2's first slab
         // ---------------- layer 2 ----------------
 #pragma unroll
@@ -254,6 +271,7 @@ __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        BF16_STAMP(4);
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
@@ -274,6 +292,7 @@ __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(
     }
     partial += __shfl_xor(partial, 32);
     if (h == 0 && p < a.B) a.out[p] = partial + a.bl[0];
+    BF16_STAMP(5);
 }
 
 // Wp[q][nt][lane][8] (bf16, RNE from fp32) with
@@ -388,8 +407,15 @@ int bf16_score(const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, i
     a.b2 = n_layers == 3 ? (const float*)(P + L.b2) : nullptr;
     a.wl = (const float*)(P + L.wl); a.bl = (const float*)(P + L.bl);
     a.out = out; a.oob = oob;
+#if NCF_BF16_STAMP
+    a.dbg = g_bf16_dbg;
+#endif
     bf16_dispatch(dims[0], dims[1], n_layers == 3 ? dims[2] : 0, &a, s);
     return check_launch("ncf_score_fused(bf16)");
 }
 
 }  // namespace ncf
+
+#if NCF_BF16_STAMP
+extern "C" void ncf_dev_set_bf16_debug_buffer(void* p) { ncf::g_bf16_dbg = (unsigned long long*)p; }
+#endif

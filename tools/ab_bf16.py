@@ -75,6 +75,21 @@ def main():
             torch.cuda.synchronize()
             times[vi].append(e0.elapsed_time(e1) * 1e3 / reps)
     for vi, fl in enumerate(variants):
+        if "NCF_BF16_STAMP=1" in fl:
+            lib, blob = libs[vi]
+            ntiles = Bsz // 32
+            dbg = torch.zeros(ntiles * 8, dtype=torch.int64, device=dev)
+            lib.ncf_dev_set_bf16_debug_buffer.argtypes = [ctypes.c_void_p]
+            lib.ncf_dev_set_bf16_debug_buffer(dbg.data_ptr())
+            for k in range(10):
+                run(lib, blob, k)
+            torch.cuda.synchronize()
+            dd = dbg.view(ntiles, 8).cpu().double() / 100.0  # us (100 MHz realtime counter)
+            t0 = dd[:, 0].min()
+            names = ["start", "after prologue barrier", "after layer 1", "after pack", "after layer 2", "end"]
+            for i, nme in enumerate(names):
+                col = dd[:, i] - t0
+                print(f"    {nme:24s}: median {col.median().item():6.2f} us  min {col.min().item():6.2f}  max {col.max().item():6.2f}")
         t = sorted(times[vi])
         med = t[len(t) // 2]
         print(f"variant {vi} [{fl or 'default'}]: median {med:.2f} us  min {t[0]:.2f} us  -> {196864*Bsz/med/1e6:.0f} TFLOP/s, {532*Bsz/med/1e3:.0f} GB/s")
