@@ -19,6 +19,9 @@
 #ifndef NCF_X_DEPTH
 #define NCF_X_DEPTH 4       // measured (interleaved A/B, cfg 2): 2 -> 72.4 us, 3 -> 70.0 us, 4 -> 69.5 us
 #endif
+#ifndef NCF_PAIR
+#define NCF_PAIR 0          // 1: MFMAs alternate between two accumulator tiles; measured no gain (70.2 vs 69.7 us): dependent 32x32x2 MFMAs issue back to back at full rate
+#endif
 #ifndef NCF_ABLATE_LOADS
 #define NCF_ABLATE_LOADS 0  // diagnostic: skip the in-loop weight / row loads (wrong results, pure MFMA stream timing)
 #endif
@@ -133,19 +136,42 @@ __global__ __launch_bounds__(NCF_WG_WAVES * 64, NCF_MIN_WAVES) void score_fused_
             // compiler's counted vmcnt waits only for the tile it is about to use.
             const int cur = q & 1, nxt = cur ^ 1;
             const f32x4 xb = x[q % XD] * (q < qa ? zA : zB);  // zero an out-of-range row at USE time
+            if (NCF_PAIR && NT1 % 2 == 0) {
 #pragma unroll
-            for (int nt = 0; nt < NT1; ++nt) {
+                for (int nt = 0; nt < NT1; nt += 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], xb[j], acc1[nt], 0, 0, 0);
-                if (q + 1 < Q1) w[nxt][nt] = NCF_ABLATE_LOADS ? w[cur][nt] : wp[((q + 1) * NT1 + nt) * 64];
+                    for (int j = 0; j < 4; ++j) {
+                        acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], xb[j], acc1[nt], 0, 0, 0);
+                        acc1[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt + 1][j], xb[j], acc1[nt + 1], 0, 0, 0);
+                    }
+                    if (q + 1 < Q1) {
+                        w[nxt][nt] = NCF_ABLATE_LOADS ? w[cur][nt] : wp[((q + 1) * NT1 + nt) * 64];
+                        w[nxt][nt + 1] = NCF_ABLATE_LOADS ? w[cur][nt + 1] : wp[((q + 1) * NT1 + nt + 1) * 64];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], xb[j], acc1[nt], 0, 0, 0);
+                    if (q + 1 < Q1) w[nxt][nt] = NCF_ABLATE_LOADS ? w[cur][nt] : wp[((q + 1) * NT1 + nt) * 64];
+                }
             }
             if (q + XD - 1 < Q1) x[(q + XD - 1) % XD] = NCF_ABLATE_LOADS ? x[q % XD] : ldg4(xsrc(q + XD - 1));
             if (!NCF_ABLATE_LOADS) {
+                if (NCF_PAIR && NT1 % 2 == 0) {
 #pragma unroll
-                for (int nt = 0; nt < NT1; ++nt) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                    for (int nt = 0; nt < NT1; nt += 2) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // 8 MFMA (two tiles alternating)
+                        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // 2 VMEM reads
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT1; ++nt) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                    }
                 }
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
@@ -153,6 +179,9 @@ __global__ __launch_bounds__(NCF_WG_WAVES * 64, NCF_MIN_WAVES) void score_fused_
         }
     }
 
+#if NCF_STAMP
+    const unsigned long long st_rL1 = __builtin_amdgcn_s_memrealtime();
+#endif
     float partial = 0.f;
     if constexpr (N2 > 0) {
         // ---- layer 2: acc2 = b2 + W2 . relu(acc1) ; acc1 registers are the B operands ----
@@ -176,22 +205,48 @@ __global__ __launch_bounds__(NCF_WG_WAVES * 64, NCF_MIN_WAVES) void score_fused_
             f32x4 hv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) hv[j] = fmaxf(acc1[kb][4 * g + j], 0.f);  // ReLU (util.py:15)
+            if (NCF_PAIR && NT2 % 2 == 0) {
 #pragma unroll
-            for (int nt = 0; nt < NT2; ++nt) {
+                for (int nt = 0; nt < NT2; nt += 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], hv[j], acc2[nt], 0, 0, 0);
-                if (q + 1 < Q2) w[nxt][nt] = NCF_ABLATE_LOADS ? w[cur][nt] : wp[((q + 1) * NT2 + nt) * 64];
-            }
-            if (!NCF_ABLATE_LOADS) {
+                    for (int j = 0; j < 4; ++j) {
+                        acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], hv[j], acc2[nt], 0, 0, 0);
+                        acc2[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt + 1][j], hv[j], acc2[nt + 1], 0, 0, 0);
+                    }
+                    if (q + 1 < Q2) {
+                        w[nxt][nt] = NCF_ABLATE_LOADS ? w[cur][nt] : wp[((q + 1) * NT2 + nt) * 64];
+                        w[nxt][nt + 1] = NCF_ABLATE_LOADS ? w[cur][nt + 1] : wp[((q + 1) * NT2 + nt + 1) * 64];
+                    }
+                }
+            } else {
 #pragma unroll
                 for (int nt = 0; nt < NT2; ++nt) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][nt][j], hv[j], acc2[nt], 0, 0, 0);
+                    if (q + 1 < Q2) w[nxt][nt] = NCF_ABLATE_LOADS ? w[cur][nt] : wp[((q + 1) * NT2 + nt) * 64];
+                }
+            }
+            if (!NCF_ABLATE_LOADS) {
+                if (NCF_PAIR && NT2 % 2 == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < NT2; nt += 2) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT2; ++nt) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#if NCF_STAMP
+        if (a.dbg && lane == 0) a.dbg[tile * 4 + 0] = __builtin_amdgcn_s_memrealtime();  // end of layer 2
+#endif
         // ---- last layer (1 wide): out = bl + sum_n wl[n] * relu(acc2[n]) ----
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt)
@@ -216,10 +271,10 @@ __global__ __launch_bounds__(NCF_WG_WAVES * 64, NCF_MIN_WAVES) void score_fused_
 #if NCF_STAMP
     if (a.dbg && lane == 0) {
         const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
-        a.dbg[tile * 4 + 0] = st_t1 - st_t0;   // shader cycles
-        a.dbg[tile * 4 + 1] = st_r1 - st_r0;   // 100 MHz ticks
-        a.dbg[tile * 4 + 2] = st_r0;
-        a.dbg[tile * 4 + 3] = st_r1;
+        (void)st_t0; (void)st_t1;
+        a.dbg[tile * 4 + 1] = st_rL1;          // end of layer 1 (100 MHz ticks)
+        a.dbg[tile * 4 + 2] = st_r0;           // wave start
+        a.dbg[tile * 4 + 3] = st_r1;           // wave end
     }
 #endif
 }

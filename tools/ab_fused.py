@@ -22,7 +22,7 @@ def build_variant(i, flags):
     out = os.path.join(ROOT, "gpurun_out", "ab")
     os.makedirs(out, exist_ok=True)
     lib = os.path.join(out, f"libncf_v{i}.so")
-    srcs = [os.path.join(B.HERE, s) for s in ("abi.hip", "mlp_fused.hip")]
+    srcs = [os.path.join(B.HERE, s) for s in ("abi.hip", "mlp_fused.hip", "mlp_bf16.hip")]
     cmd = [B._hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared", "-o", lib] + flags.split() + srcs
     subprocess.check_call(cmd)
     return lib
@@ -91,13 +91,15 @@ def main():
             for k in range(20):
                 run(lib, blob, k)
             torch.cuda.synchronize()
-            dd = dbg.view(ntiles, 4).cpu().double()
-            cyc, rt = dd[:, 0], dd[:, 1]
-            span = (dd[:, 3].max() - dd[:, 2].min()).item() / 100.0
-            clk = (cyc / rt * 100).median().item()
-            print(f"  stamps: wave cycles median {cyc.median().item():.0f} min {cyc.min().item():.0f} max {cyc.max().item():.0f}; "
-                  f"clock ~{clk:.0f} MHz; wave time median {rt.median().item()/100:.2f} us; first-start..last-end {span:.2f} us; "
-                  f"start spread {(dd[:,2].max()-dd[:,2].min()).item()/100:.2f} us")
+            dd = dbg.view(ntiles, 4).cpu().double() / 100.0   # us
+            t0 = dd[:, 2].min()
+            for nme, col in (("wave start", dd[:, 2]), ("end of layer 1", dd[:, 1]), ("end of layer 2", dd[:, 0]), ("wave end", dd[:, 3])):
+                c = col - t0
+                print(f"    {nme:16s}: median {c.median().item():6.2f} us  min {c.min().item():6.2f}  max {c.max().item():6.2f}")
+            d1 = dd[:, 1] - dd[:, 2]
+            d2 = dd[:, 0] - dd[:, 1]
+            print(f"    per wave: start->L1 end median {d1.median().item():.2f} (min {d1.min().item():.2f} max {d1.max().item():.2f}); "
+                  f"L2 median {d2.median().item():.2f} (min {d2.min().item():.2f} max {d2.max().item():.2f}); tail {(dd[:,3]-dd[:,0]).median().item():.2f}")
         t = sorted(times[vi])
         med = t[len(t) // 2]
         print(f"variant {vi} [{fl or 'default'}]: median {med:.2f} us  min {t[0]:.2f} us  -> {131328*Bsz/med/1e6:.1f} TFLOP/s")
