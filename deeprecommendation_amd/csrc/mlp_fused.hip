@@ -280,6 +280,168 @@ __global__ __launch_bounds__(NCF_WG_WAVES * 64, NCF_MIN_WAVES) void score_fused_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Small-batch variant.  The main kernel gives one wave a whole 32-pair tile (1024 MFMAs, ~27 us): below ~1000 tiles the
+// chip is mostly idle and the latency floor is one tile.  Here the FOUR waves of a workgroup share one tile: each wave
+// computes a quarter of layer 1's neurons, the ReLU'd activations go through LDS as [k-chunk][pair] float4 (exactly the
+// B-operand fragments of layer 2), each wave computes a quarter of layer 2, and wave 0 finishes the 1-wide layer from
+// LDS in the SAME operation order as the main kernel — results are bit-identical to it (and to oracle/ncf_oracle_c.c).
+template <int K0, int N1, int N2>
+__global__ __launch_bounds__(256) void score_fused_small_f32_kernel(FusedArgs a) {
+    constexpr int NT1 = N1 / 32, Q1 = K0 / 8, NT2 = N2 / 32, Q2 = N1 / 8;
+    constexpr int T1 = NT1 / 4;                 // layer-1 tiles per wave
+    constexpr int T2 = (NT2 + 3) / 4;           // layer-2 tiles per wave (waves beyond NT2 idle in layer 2)
+    constexpr int WD = 3, XD = 4;               // weight / row prefetch rings (k-steps)
+    __shared__ __attribute__((aligned(16))) f32x4 h1s[N1 / 4][32];
+    __shared__ __attribute__((aligned(16))) f32x4 h2s[(N2 > 0 ? N2 : 4) / 4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t p = (int64_t)blockIdx.x * 32 + m;
+    const int64_t pc = p < a.B ? p : a.B - 1;
+
+    const int64_t ia = a.idxA ? a.idxA[pc] : pc;
+    const bool okA = (ia >= 0) & (ia < a.rowsA);
+    const float* rowA = a.tabA + (okA ? ia : 0) * a.ldA + 4 * h;
+    const int qa = a.EA / 8;
+    const float* rowB = rowA;
+    bool okB = true;
+    if (qa < Q1) {
+        const int64_t ib = a.idxB ? a.idxB[pc] : pc;
+        okB = (ib >= 0) & (ib < a.rowsB);
+        rowB = a.tabB + (okB ? ib : 0) * a.ldB + 4 * h;
+    }
+    if (!(okA & okB) && a.oob && wave == 0 && p < a.B) *a.oob = 1;
+    const float zA = okA ? 1.f : 0.f, zB = okB ? 1.f : 0.f;
+    auto xsrc = [&](int q) { return q < qa ? rowA + 8 * q : rowB + 8 * (q - qa); };
+
+    // ---- layer 1: this wave's tiles nt = wave*T1 + t ----
+    f32x16 acc1[T1];
+#pragma unroll
+    for (int t = 0; t < T1; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bb = ldg4(a.b1 + 32 * (wave * T1 + t) + 8 * g + 4 * h);
+            acc1[t][4 * g + 0] = bb[0]; acc1[t][4 * g + 1] = bb[1];
+            acc1[t][4 * g + 2] = bb[2]; acc1[t][4 * g + 3] = bb[3];
+        }
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp1) + lane;
+        f32x4 w[WD][T1];
+        f32x4 x[XD];
+#pragma unroll
+        for (int s0 = 0; s0 < WD - 1; ++s0)
+            if (s0 < Q1) {
+#pragma unroll
+                for (int t = 0; t < T1; ++t) w[s0][t] = wp[(s0 * NT1 + wave * T1 + t) * 64];
+            }
+#pragma unroll
+        for (int s0 = 0; s0 < XD - 1; ++s0)
+            if (s0 < Q1) x[s0] = ldg4(xsrc(s0));
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) {
+            if (q + WD - 1 < Q1) {
+#pragma unroll
+                for (int t = 0; t < T1; ++t) w[(q + WD - 1) % WD][t] = wp[((q + WD - 1) * NT1 + wave * T1 + t) * 64];
+            }
+            if (q + XD - 1 < Q1) x[(q + XD - 1) % XD] = ldg4(xsrc(q + XD - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 xb = x[q % XD] * (q < qa ? zA : zB);
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q % WD][t][j], xb[j], acc1[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ReLU'd activations -> LDS in layer-2 B-fragment order: chunk (8nt + 2g + h) of pair m = neurons 32nt+8g+4h+0..3
+#pragma unroll
+    for (int t = 0; t < T1; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc1[t][4 * g + j], 0.f);
+            h1s[8 * (wave * T1 + t) + 2 * g + h][m] = v;
+        }
+    __syncthreads();
+
+    if constexpr (N2 > 0) {
+        f32x16 acc2[T2];
+        const bool l2_active = wave < NT2;      // wave-uniform
+        if (l2_active) {
+#pragma unroll
+            for (int t = 0; t < T2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nt = wave + 4 * t;
+                    const f32x4 bb = ldg4(a.b2 + 32 * (nt < NT2 ? nt : 0) + 8 * g + 4 * h);
+                    acc2[t][4 * g + 0] = bb[0]; acc2[t][4 * g + 1] = bb[1];
+                    acc2[t][4 * g + 2] = bb[2]; acc2[t][4 * g + 3] = bb[3];
+                }
+            const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp2) + lane;
+            f32x4 w[WD][T2];
+#pragma unroll
+            for (int s0 = 0; s0 < WD - 1; ++s0)
+#pragma unroll
+                for (int t = 0; t < T2; ++t) {
+                    const int nt = wave + 4 * t;
+                    w[s0][t] = wp[(s0 * NT2 + (nt < NT2 ? nt : 0)) * 64];
+                }
+            f32x4 hvr[2];
+            hvr[0] = h1s[h][m];
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) {
+                if (q + WD - 1 < Q2) {
+#pragma unroll
+                    for (int t = 0; t < T2; ++t) {
+                        const int nt = wave + 4 * t;
+                        w[(q + WD - 1) % WD][t] = wp[((q + WD - 1) * NT2 + (nt < NT2 ? nt : 0)) * 64];
+                    }
+                }
+                if (q + 1 < Q2) hvr[(q + 1) & 1] = h1s[2 * (q + 1) + h][m];
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 hv = hvr[q & 1];
+#pragma unroll
+                for (int t = 0; t < T2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q % WD][t][j], hv[j], acc2[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                const int nt = wave + 4 * t;
+                if (nt < NT2) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc2[t][4 * g + j], 0.f);
+                        h2s[8 * nt + 2 * g + h][m] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    // ---- last layer, same chain order as the main kernel: per lane half over nt, g, j; then half 0 + half 1 ----
+    constexpr int NTL = (N2 > 0 ? N2 : N1) / 32;
+    float partial = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ww = ldg4(a.wl + 32 * nt + 8 * g + 4 * h);
+            const f32x4 v = (N2 > 0) ? h2s[8 * nt + 2 * g + h][m] : h1s[8 * nt + 2 * g + h][m];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) partial = fmaf(ww[j], v[j], partial);
+        }
+    partial += __shfl_xor(partial, 32);
+    if (h == 0 && p < a.B) a.out[p] = partial + a.bl[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Folded first layer (opt-in, inference-time weight folding): with frozen weights
 //     relu(W1 . cat(a, b) + b1) = relu(PA[ia] + PB[ib]),   PA = TA . W1[:, :EA]^T + b1,   PB = TB . W1[:, EA:]^T
 // so layer 1 needs no matrix work at all: the "embedding" rows become N1-wide pre-activations (4x the table bytes at
@@ -545,9 +707,19 @@ static BlobLayout blob_layout(const int* dims, int n_layers) {
 }
 
 typedef void (*fused_fn)(FusedArgs);
+#ifndef NCF_SMALL_TILES
+#define NCF_SMALL_TILES 768   // below this many 32-pair tiles the 4-waves-per-tile kernel is used (measured crossover)
+#endif
+
 template <int K0, int N1, int N2>
 static void launch_inst(const FusedArgs& a, hipStream_t s) {
     const int64_t tiles = (a.B + 31) / 32;
+    if constexpr ((N1 / 32) % 4 == 0 && (N2 / 32) <= 4) {
+        if (tiles < NCF_SMALL_TILES) {
+            hipLaunchKernelGGL((score_fused_small_f32_kernel<K0, N1, N2>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+            return;
+        }
+    }
     const unsigned blocks = (unsigned)((tiles + NCF_WG_WAVES - 1) / NCF_WG_WAVES);
     hipLaunchKernelGGL((score_fused_f32_kernel<K0, N1, N2>), dim3(blocks), dim3(NCF_WG_WAVES * 64), 0, s, a);
 }

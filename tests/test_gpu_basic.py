@@ -380,3 +380,28 @@ def test_score_fused_bit_exact_vs_kernel_order_c_oracle(native, gpu, E, hidden):
     out = native.score_fused(ta.to(gpu), ia.to(gpu), tb.to(gpu), ib.to(gpu), packed)
     ref = c_oracle.score_fused_f32(ta, tb, ia, ib, ws, bs)
     assert torch.equal(out.cpu(), ref), f"max abs diff {(out.cpu() - ref).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("E,hidden", [(64, [256, 128]), (32, [256]), (64, [128, 64]), (128, [256, 128])])
+def test_small_batch_kernel_is_bit_identical_to_main_kernel(native, gpu, E, hidden):
+    """Below NCF_SMALL_TILES tiles ncf_score_fused runs the 4-waves-per-tile kernel, above it the one-wave-per-tile
+    kernel.  Same operation order by construction: the same pairs scored in one big batch and in small batches must
+    agree bit for bit, and both equal the kernel-order C oracle."""
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(E * 7 + len(hidden))
+    dims = [2 * E] + hidden + [1]
+    B = 30000  # 938 tiles -> main kernel; chunks of 999 -> small kernel (ragged last tile)
+    ta = torch.randn(900, E, generator=g) * 0.5
+    tb = torch.randn(400, E, generator=g) * 0.5
+    ia = torch.randint(0, 900, (B,), generator=g)
+    ib = torch.randint(0, 400, (B,), generator=g)
+    ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(len(dims) - 1)]
+    packed = native.PackedMLP([w.to(gpu) for w in ws], [b.to(gpu) for b in bs])
+    tag, tbg, iag, ibg = ta.to(gpu), tb.to(gpu), ia.to(gpu), ib.to(gpu)
+    big = native.score_fused(tag, iag, tbg, ibg, packed)
+    small = torch.cat([native.score_fused(tag, iag[s:s + 999].contiguous(), tbg, ibg[s:s + 999].contiguous(), packed)
+                       for s in range(0, B, 999)])
+    assert torch.equal(big, small)
+    ref = c_oracle.score_fused_f32(ta, tb, ia, ib, ws, bs)
+    assert torch.equal(big.cpu(), ref)
