@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fold", action="store_true",
                     help="opt-in: fold the first MLP layer into the tables (BasicNCF.set_fold_first_layer); NOT the default line")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "train2"],
                     help="cfg2 = BASELINE headline (default); cfg3 / cfg4 = the other single-GPU configs (bench_extra.py)")
     args = ap.parse_args()
     if args.workload != "cfg2":

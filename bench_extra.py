@@ -234,9 +234,49 @@ def run_cfg5(args, device):
         dist.destroy_process_group()
 
 
+def run_train2(args, device):
+    """Training step on the cfg-2 shape: BasicNCF 1 M x 100 k, emb 64, batch 65 536, MLP [256,128],
+    dropout 0.2, MSE-sum loss, Adam over every parameter (the reference's optimiser, train.py:55).  Forward + backward
+    of the gather and Linear(+ReLU) layers on the HIP autograd blocks, next to the same step with plain torch ops
+    (rocBLAS / ATen) on the same GPU.  Unit: trained pairs/s."""
+    import bench
+    res = {}
+    for mode in ("hip_blocks", "torch_ops"):
+        model = bench.make_model(device).train()
+        model.train_with_torch_ops = mode == "torch_ops"
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        batches = bench.make_batches(device, 0)
+        g = torch.Generator(device=device).manual_seed(5)
+        y = torch.rand((bench.B, 1), device=device, generator=g) * 5
+
+        def step(k):
+            iu, ii = batches[k % len(batches)]
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.mse_loss(model(iu, ii), y, reduction="sum")
+            loss.backward()
+            opt.step()
+
+        wall, _ = _time_steps(step, args.warmup, args.steps)
+        res[mode] = wall / args.steps
+        del model, opt
+        torch.cuda.empty_cache()
+    line = {"metric": "trained user-item pairs/sec (forward + backward + Adam)", "value": bench.B / res["hip_blocks"], "unit": "pairs/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["hip_blocks"] * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "train2: BasicNCF 1M x 100k, emb 64, batch 65536, MLP 128-256-128-1, dropout 0.2, MSE, Adam (dense)",
+                       "same_step_with_torch_ops_ms": res["torch_ops"] * 1e3,
+                       "note": "the step is dominated by dense full-table work both ways (T = W^T + b, dense table gradients, "
+                               "dense Adam over 71 M parameters), as in the reference's dense-Linear formulation"}}
+    print(json.dumps(line), flush=True)
+
+
 def main(args):
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(device)
+    if args.workload == "train2":
+        if args.steps == 400:
+            args.steps, args.warmup = 20, 3
+        return run_train2(args, device)
     if args.workload == "cfg5":
         if args.steps == 400:
             args.steps, args.warmup = 100, 10

@@ -1,0 +1,78 @@
+"""torch.autograd wrappers that run a TRAINING step's forward and backward on the HIP kernels.
+
+Only the differentiable building blocks of the scoring path are wrapped — the embedding gather and the Linear(+ReLU)
+layers; loss, dropout masks and the optimizer stay torch ops (the reference's train loop, train.py:95-110, drives them).
+  GatherConcatFn : forward ncf_gather_concat;  backward ncf_scatter_add_rows into dense table gradients
+  LinearFn       : forward ncf_linear_forward (ReLU fused in the epilogue);
+                   backward dX = dY . W (row-streaming GEMM with W^T), dW = dY^T . X (ncf_gemm_tn, ordered split over
+                   the batch), db = ncf_colsum, ReLU mask = ncf_relu_backward
+"""
+import torch
+
+from . import native
+
+
+class GatherConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tabA, idxA, tabB, idxB):
+        ctx.save_for_backward(idxA, idxB)
+        ctx.shapes = (tuple(tabA.shape), tuple(tabB.shape))
+        return native.gather_concat(tabA.contiguous(), idxA, tabB.contiguous(), idxB)
+
+    @staticmethod
+    def backward(ctx, dX):
+        idxA, idxB = ctx.saved_tensors
+        (ra, ea), (rb, eb) = ctx.shapes
+        dX = dX.contiguous()
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            dA = torch.zeros((ra, ea), dtype=torch.float32, device=dX.device)
+            native.scatter_add_rows(dX[:, :ea], idxA, dA)
+        if ctx.needs_input_grad[2]:
+            dB = torch.zeros((rb, eb), dtype=torch.float32, device=dX.device)
+            native.scatter_add_rows(dX[:, ea:], idxB, dB)
+        return dA, None, dB, None
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x = x.contiguous()
+        w = weight.contiguous()
+        y = native.linear_act(x, w, None if bias is None else bias.contiguous(), relu)
+        ctx.relu = bool(relu)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dY):
+        x, w, y = ctx.saved_tensors
+        dY = dY.contiguous()
+        if ctx.relu:
+            dY = native.relu_backward_(dY.clone(), y)
+        dX = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dX = native.linear_act(dY, w.t().contiguous(), None, False)   # dX = dY . W
+        if ctx.needs_input_grad[1]:
+            dW = native.gemm_tn(dY, x)                                   # dW = dY^T . X
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = native.colsum(dY)
+        return dX, dW, db, None
+
+
+def mlp_train(seq: torch.nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """A build_MLP_layers Sequential (Linear, [ReLU, Dropout?, Linear]*) applied with the HIP autograd blocks: every
+    Linear that is followed by a ReLU fuses it; Dropout modules run as the torch ops they are."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, torch.nn.Linear):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU)
+            x = LinearFn.apply(x, m.weight, m.bias, fuse)
+            i += 2 if fuse else 1
+        else:
+            x = m(x)
+            i += 1
+    return x

@@ -319,3 +319,11 @@ extern "C" int ncf_mlp_forward(int dtype, const void* x, int64_t B, int64_t ldx,
     }
     return NCF_OK;
 }
+
+extern "C" int ncf_linear_forward(int dtype, const void* x, int64_t M, int64_t ldx, const void* W, const void* b, int K, int N,
+                                  int relu, void* out, int64_t ldo, ncf_stream_t stream) {
+    if (dtype != NCF_F32) return fail(NCF_EUNSUPPORTED, "ncf_linear_forward: fp32 only");
+    if (M == 0) return NCF_OK;
+    if (M < 0 || K <= 0 || N <= 0 || !x || !W || !out || ldx < K || ldo < N) return fail(NCF_EINVAL, "ncf_linear_forward: bad argument");
+    return launch_linear((const float*)x, ldx, (const float*)W, K, (const float*)b, (float*)out, ldo, M, N, K, relu != 0, (hipStream_t)stream);
+}

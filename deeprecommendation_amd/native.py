@@ -51,6 +51,12 @@ SIGNATURES = {
     "ncf_score_folded_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "ncf_score_folded": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p,
                                   _c_p, _c_p, _c_p]),
+    "ncf_linear_forward": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_i64, _c_p]),
+    "ncf_gemm_tn_workspace_bytes": (_c_size, [_c_i64, _c_int, _c_int]),
+    "ncf_gemm_tn": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_p, _c_i64, _c_p, _c_size, _c_p]),
+    "ncf_colsum": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
+    "ncf_relu_backward": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_p]),
+    "ncf_scatter_add_rows": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_l2_normalize_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p]),
 }
 
@@ -460,3 +466,64 @@ def edge_softmax_csr(rowptr: torch.Tensor, col: torch.Tensor, attr: Optional[tor
         out = torch.empty(max(col.numel(), 1), dtype=torch.float32, device=s.device)[:col.numel()]
     _check(lib.ncf_edge_softmax_csr(_ptr(rowptr), _ptr(col), _ptr(attr), _ptr(s), rowptr.numel() - 1, s.numel(), _ptr(out), _stream(s)))
     return out
+
+
+def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
+    """One layer with a selectable fused ReLU (the autograd wrappers keep every layer's output)."""
+    lib = load_library()
+    _dev(x, "x")
+    if x.dtype != torch.float32 or weight.dtype != torch.float32 or not weight.is_contiguous():
+        raise TypeError("linear_act needs fp32 activations and a contiguous fp32 weight")
+    M, K, ldx = _rows2d(x, "x")
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError("weight / activation widths disagree")
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _check(lib.ncf_linear_forward(NCF_F32, _ptr(x), M, ldx, _ptr(weight), _ptr(bias), K, N, 1 if relu else 0, _ptr(out), N, _stream(x)))
+    return out
+
+
+# ------------------------------------------------------------------ backward (training step)
+def gemm_tn(A: torch.Tensor, Bm: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (N1, N2) = A^T @ Bm for A (M, N1), Bm (M, N2): the weight gradient dW = dY^T X."""
+    lib = load_library()
+    _dev(A, "A"), _dev(Bm, "B")
+    M, N1, lda = _rows2d(A, "A")
+    M2, N2, ldb = _rows2d(Bm, "B")
+    if M != M2 or A.dtype != torch.float32 or Bm.dtype != torch.float32:
+        raise ValueError("gemm_tn needs fp32 operands with the same number of rows")
+    if out is None:
+        out = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
+    nb = lib.ncf_gemm_tn_workspace_bytes(M, N1, N2)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=A.device)
+    _check(lib.ncf_gemm_tn(_ptr(A), lda, _ptr(Bm), ldb, M, N1, N2, _ptr(out), out.stride(0), _ptr(ws), nb, _stream(A)))
+    return out
+
+
+def colsum(X: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    _dev(X, "X")
+    M, N, ld = _rows2d(X, "X")
+    out = torch.empty(N, dtype=torch.float32, device=X.device)
+    _check(lib.ncf_colsum(_ptr(X), ld, M, N, _ptr(out), _stream(X)))
+    return out
+
+
+def relu_backward_(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    M, N, ldd = _rows2d(dY, "dY")
+    _, _, ldy = _rows2d(Y, "Y")
+    _check(lib.ncf_relu_backward(_ptr(dY), ldd, _ptr(Y), ldy, M, N, _stream(dY)))
+    return dY
+
+
+def scatter_add_rows(src: torch.Tensor, idx: Optional[torch.Tensor], dst: torch.Tensor) -> torch.Tensor:
+    """dst[idx[p], :] += src[p, :] (src may be a column slice of a wider matrix)."""
+    lib = load_library()
+    _dev(src, "src"), _dev(dst, "dst")
+    B, E, lds = _rows2d(src, "src")
+    rows, E2, ldd = _rows2d(dst, "dst")
+    if E != E2:
+        raise ValueError("row widths disagree")
+    _check(lib.ncf_scatter_add_rows(_ptr(src), lds, _ptr(_idx(idx)), B, E, _ptr(dst), ldd, rows, _ptr(_oob_flag(src.device)), _stream(src)))
+    return dst

@@ -137,7 +137,17 @@ class BasicNCF(_ScoringMixin, NCF):
         return self._score(u, None, i, None)  # cat(user, item): basic_ncf.py:40
 
     def _forward_train(self, X_user, X_item, indexed):
-        """Differentiable torch path for a training step (dropout active, autograd recording)."""
+        """Training step (dropout active, autograd recording).  On CUDA tensors the gather and the Linear(+ReLU) layers run
+        forward AND backward on the HIP kernels through deeprecommendation_amd.autograd; on CPU it is plain torch."""
+        if X_user.is_cuda and not getattr(self, "train_with_torch_ops", False):
+            from ...autograd import GatherConcatFn, LinearFn, mlp_train
+            ue, ie = self.user_embeddings[0], self.item_embeddings[0]
+            if indexed:
+                x = GatherConcatFn.apply(ue.weight.t() + ue.bias, X_user.contiguous(), ie.weight.t() + ie.bias, X_item.contiguous())
+            else:
+                x = torch.cat((LinearFn.apply(X_user.float(), ue.weight, ue.bias, False),
+                               LinearFn.apply(X_item.float(), ie.weight, ie.bias, False)), dim=1)
+            return mlp_train(self.MLP, x)
         if indexed:
             ue, ie = self.user_embeddings[0], self.item_embeddings[0]
             user_emb = ue.weight.t()[X_user] + ue.bias

@@ -221,6 +221,27 @@ int ncf_attn_forward(int mode,
 int ncf_l2_normalize_rows(const float* dev_x, int64_t ldx, int64_t R, int E, float* dev_out, int64_t ldout,
                           ncf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Backward (training step).  The reference trains through torch autograd (train.py:95-110); these
+ * are the gradient kernels of K1 / K2.  fp32.
+ *   dX = dY . W            : ncf_mlp_forward(n_layers = 1) with the transposed weight (no dedicated entry)
+ *   dW = dY^T . X          : ncf_gemm_tn(A = dY (M, N1), B = X (M, N2)) -> (N1, N2); ordered split over M, deterministic
+ *   db = column sums of dY : ncf_colsum
+ *   ReLU                   : ncf_relu_backward zeroes dY where the forward output was <= 0
+ *   embedding rows         : ncf_scatter_add_rows  dst[idx[p], :] += src[p, :]  (float atomics: order-dependent last bits)
+ * ------------------------------------------------------------------------------------------------ */
+/* out = act(x . W^T + b) for ONE layer with the activation selectable (relu != 0 -> ReLU): the single-layer form of
+ * ncf_mlp_forward used by the autograd wrappers, which need every layer's output (util.py:12-17 one Linear at a time). */
+int ncf_linear_forward(int dtype, const void* dev_x, int64_t M, int64_t ldx, const void* dev_W, const void* dev_b, int K, int N,
+                       int relu, void* dev_out, int64_t ldo, ncf_stream_t stream);
+size_t ncf_gemm_tn_workspace_bytes(int64_t M, int N1, int N2);
+int ncf_gemm_tn(const float* dev_A, int64_t lda, const float* dev_B, int64_t ldb, int64_t M, int N1, int N2,
+                float* dev_out, int64_t ldo, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
+int ncf_colsum(const float* dev_X, int64_t ldx, int64_t M, int N, float* dev_out, ncf_stream_t stream);
+int ncf_relu_backward(float* dev_dY, int64_t ld_dY, const float* dev_Y, int64_t ld_Y, int64_t M, int N, ncf_stream_t stream);
+int ncf_scatter_add_rows(const float* dev_src, int64_t ld_src, const int64_t* dev_idx, int64_t B, int E,
+                         float* dev_dst, int64_t ld_dst, int64_t rows, int32_t* dev_oob_flag, ncf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
