@@ -58,17 +58,21 @@ __global__ void gemm_tn_reduce_kernel(const float* __restrict__ partial, int sli
     }
 }
 
-// out[n] = sum_m X[m][n]: one block per 64 columns, rows strided over the block's 4 waves, fixed-order LDS combine.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int N, float* __restrict__ out) {
+// partial[slice][n] = sum over the slice's rows of X[m][n]: block (x = 64 columns, y = row slice), rows strided over the
+// block's 4 waves, fixed-order LDS combine; gemm_tn_reduce_kernel then adds the slices in order (deterministic).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int N, int64_t rows_per_slice,
+                                                     float* __restrict__ partial) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
+    const int64_t m_lo = (int64_t)blockIdx.y * rows_per_slice;
+    const int64_t m_hi = m_lo + rows_per_slice < M ? m_lo + rows_per_slice : M;
     float s = 0.f;
     if (n < N)
-        for (int64_t m = wave; m < M; m += 4) s += X[m * ldx + n];
+        for (int64_t m = m_lo + wave; m < m_hi; m += 4) s += X[m * ldx + n];
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && n < N) out[n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (wave == 0 && n < N) partial[(size_t)blockIdx.y * N + n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // dY[m][n] = Y[m][n] > 0 ? dY[m][n] : 0   (backward of the ReLU fused into the forward GEMM epilogue)
@@ -129,9 +133,27 @@ extern "C" int ncf_gemm_tn(const float* A, int64_t lda, const float* Bm, int64_t
     return check_launch("ncf_gemm_tn");
 }
 
-extern "C" int ncf_colsum(const float* X, int64_t ldx, int64_t M, int N, float* out, ncf_stream_t stream) {
+static int64_t colsum_slices(int64_t M) {
+    int64_t slices = (M + 255) / 256;
+    return slices > 256 ? 256 : (slices < 1 ? 1 : slices);
+}
+
+extern "C" size_t ncf_colsum_workspace_bytes(int64_t M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)colsum_slices(M) * N * sizeof(float);
+}
+
+extern "C" int ncf_colsum(const float* X, int64_t ldx, int64_t M, int N, float* out, void* workspace, size_t ws_bytes, ncf_stream_t stream) {
     if (N <= 0 || M < 0 || !out || (M > 0 && (!X || ldx < N))) return fail(NCF_EINVAL, "ncf_colsum: bad argument");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, ldx, M, N, out);
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) return hipMemsetAsync(out, 0, N * sizeof(float), s) == hipSuccess ? NCF_OK : fail(NCF_ELAUNCH, "ncf_colsum: memset failed");
+    const size_t need = ncf_colsum_workspace_bytes(M, N);
+    if (!workspace || ws_bytes < need) return fail(NCF_EWORKSPACE, "ncf_colsum: workspace %zu < %zu bytes", ws_bytes, need);
+    const int64_t slices = colsum_slices(M);
+    const int64_t rps = (M + slices - 1) / slices;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (unsigned)slices), dim3(256), 0, s, X, ldx, M, N, rps, (float*)workspace);
+    int64_t blocks = (N + 255) / 256;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, (int)slices, (int64_t)N, out, (int64_t)N, N);
     return check_launch("ncf_colsum");
 }
 

@@ -54,7 +54,8 @@ SIGNATURES = {
     "ncf_linear_forward": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_i64, _c_p]),
     "ncf_gemm_tn_workspace_bytes": (_c_size, [_c_i64, _c_int, _c_int]),
     "ncf_gemm_tn": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_p, _c_i64, _c_p, _c_size, _c_p]),
-    "ncf_colsum": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
+    "ncf_colsum_workspace_bytes": (_c_size, [_c_i64, _c_int]),
+    "ncf_colsum": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_size, _c_p]),
     "ncf_relu_backward": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_p]),
     "ncf_scatter_add_rows": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_l2_normalize_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p]),
@@ -505,7 +506,9 @@ def colsum(X: torch.Tensor) -> torch.Tensor:
     _dev(X, "X")
     M, N, ld = _rows2d(X, "X")
     out = torch.empty(N, dtype=torch.float32, device=X.device)
-    _check(lib.ncf_colsum(_ptr(X), ld, M, N, _ptr(out), _stream(X)))
+    nb = lib.ncf_colsum_workspace_bytes(M, N)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=X.device)
+    _check(lib.ncf_colsum(_ptr(X), ld, M, N, _ptr(out), _ptr(ws), nb, _stream(X)))
     return out
 
 

@@ -23,12 +23,6 @@ class MF(_ScoringMixin, NCF):
     def forward(self, X_user, X_item):
         indexed = X_user.dtype == torch.int64 and X_user.dim() == 1
         if not use_native(self):
-            if indexed and X_user.is_cuda and not getattr(self, "train_with_torch_ops", False):
-                from ...autograd import GatherConcatFn  # gather forward + scatter-add backward on the HIP kernels
-                ue, ie = self.user_embeddings[0], self.item_embeddings[0]
-                x = GatherConcatFn.apply(ue.weight.t() + ue.bias, X_user.contiguous(), ie.weight.t() + ie.bias, X_item.contiguous())
-                E = ue.out_features
-                return (x[:, :E] * x[:, E:]).sum(dim=1, keepdim=True)
             if indexed:
                 ue, ie = self.user_embeddings[0], self.item_embeddings[0]
                 u, i = ue.weight.t()[X_user] + ue.bias, ie.weight.t()[X_item] + ie.bias

@@ -237,7 +237,9 @@ int ncf_linear_forward(int dtype, const void* dev_x, int64_t M, int64_t ldx, con
 size_t ncf_gemm_tn_workspace_bytes(int64_t M, int N1, int N2);
 int ncf_gemm_tn(const float* dev_A, int64_t lda, const float* dev_B, int64_t ldb, int64_t M, int N1, int N2,
                 float* dev_out, int64_t ldo, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
-int ncf_colsum(const float* dev_X, int64_t ldx, int64_t M, int N, float* dev_out, ncf_stream_t stream);
+size_t ncf_colsum_workspace_bytes(int64_t M, int N);
+int ncf_colsum(const float* dev_X, int64_t ldx, int64_t M, int N, float* dev_out, void* dev_workspace, size_t workspace_bytes,
+               ncf_stream_t stream);
 int ncf_relu_backward(float* dev_dY, int64_t ld_dY, const float* dev_Y, int64_t ld_Y, int64_t M, int N, ncf_stream_t stream);
 int ncf_scatter_add_rows(const float* dev_src, int64_t ld_src, const int64_t* dev_idx, int64_t B, int E,
                          float* dev_dst, int64_t ld_dst, int64_t rows, int32_t* dev_oob_flag, ncf_stream_t stream);

@@ -95,3 +95,23 @@ def test_scatter_add_rows(gpu):
     ref = dst.clone().double().index_add_(0, idx, src[:, 32:].double())
     out = native.scatter_add_rows(src.to(gpu)[:, 32:], idx.to(gpu), dst.to(gpu))
     assert float((out.cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_gather_concat_autograd_block(gpu):
+    """GatherConcatFn (row-gather forward, scatter-add backward) for tables kept in table layout."""
+    from deeprecommendation_amd.autograd import GatherConcatFn
+    g = torch.Generator().manual_seed(0)
+    ta = torch.randn(300, 64, generator=g, requires_grad=True)
+    tb = torch.randn(100, 32, generator=g, requires_grad=True)
+    ia = torch.randint(0, 300, (2000,), generator=g)
+    ib = torch.randint(0, 100, (2000,), generator=g)
+    wgt = torch.randn(2000, 96, generator=g)
+    (torch.cat((ta[ia], tb[ib]), 1) * wgt).sum().backward()
+    ga, gb = ta.grad.clone(), tb.grad.clone()
+    tag = ta.detach().to(gpu).requires_grad_(True)
+    tbg = tb.detach().to(gpu).requires_grad_(True)
+    out = GatherConcatFn.apply(tag, ia.to(gpu), tbg, ib.to(gpu))
+    assert torch.equal(out.detach().cpu(), torch.cat((ta[ia], tb[ib]), 1).detach())
+    (out * wgt.to(gpu)).sum().backward()
+    assert float((tag.grad.cpu() - ga).abs().max()) <= 1e-5 * float(ga.abs().max())
+    assert float((tbg.grad.cpu() - gb).abs().max()) <= 1e-5 * float(gb.abs().max())
