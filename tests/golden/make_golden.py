@@ -81,6 +81,19 @@ def main():
         _save(tag, user_pos=up, item_pos=ip, out=out.numpy(),
               kwargs=np.array(json.dumps(m.kwargs)), **_state_arrays(m))
 
+    # kernel-shaped cases: these dims hit the fused / small-batch / folded HIP instances directly
+    for tag, E, mlp in (("g1_basic_onehot_e64", 64, [256, 128]), ("g1_basic_onehot_e128", 128, [256, 128]),
+                        ("g1_basic_onehot_e64_h256", 64, [256])):
+        torch.manual_seed(105)
+        U, I = 600, 400
+        m = BasicNCF(item_dim=I, user_dim=U, item_emb=E, user_emb=E, mlp_dense_layers=mlp).eval()
+        rng = np.random.default_rng(12)
+        up = rng.integers(0, U, 700)
+        ip = rng.integers(0, I, 700)
+        with torch.no_grad():
+            out = m(onehot(up, U), onehot(ip, I))
+        _save(tag, user_pos=up, item_pos=ip, out=out.numpy(), kwargs=np.array(json.dumps(m.kwargs)), **_state_arrays(m))
+
     torch.manual_seed(102)
     m = BasicNCF(item_dim=24, user_dim=24, item_emb=16, user_emb=8, mlp_dense_layers=[32, 16]).eval()
     Xu = torch.rand(48, 24)
@@ -123,6 +136,22 @@ def main():
         torch.manual_seed(104)
         m = AttentionNCF(item_dim=20, item_emb=16, user_emb=16, mlp_dense_layers=[32, 16], **kw).eval()
         cand, rated, um = att_inputs(8, 12, 20, 9)
+        with torch.no_grad():
+            out, att = m(cand, rated, um, return_attention_weights=True)
+        _save(tag, candidate_items=cand.numpy(), rated_items=rated.numpy(), user_matrix=um.numpy(),
+              out=out.numpy(), att=att.numpy(), kwargs=np.array(json.dumps(m.kwargs)), **_state_arrays(m))
+
+    # kernel-shaped attention cases (vector paths of the HIP kernel: A = 128, IE = UE = 64 / 128)
+    for tag, Fdim, IE, A, B, I in (("g3_att_vec64", 50, 64, 128, 64, 200), ("g3_att_vec128", 40, 128, 128, 33, 129)):
+        torch.manual_seed(106)
+        m = AttentionNCF(item_dim=Fdim, item_emb=IE, user_emb=IE, att_dense=A, mlp_dense_layers=[256, 128]).eval()
+        g = torch.Generator().manual_seed(13)
+        rated = torch.rand(I, Fdim, generator=g)
+        cand = torch.rand(B, Fdim, generator=g)
+        um = torch.zeros(B, I)
+        mask = torch.rand(B, I, generator=g) < 0.3
+        um[mask] = (torch.randint(1, 11, (B, I), generator=g).float() * 0.5 - 2.9)[mask]
+        um[0] = 0.0
         with torch.no_grad():
             out, att = m(cand, rated, um, return_attention_weights=True)
         _save(tag, candidate_items=cand.numpy(), rated_items=rated.numpy(), user_matrix=um.numpy(),

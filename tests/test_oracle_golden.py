@@ -16,7 +16,18 @@ from conftest import GOLDEN, load_golden, onehot
 from oracle import ncf_oracle as O
 
 
-@pytest.mark.parametrize("name", ["g1_basic_onehot_small", "g1_basic_onehot_e32", "g1_basic_onehot_nodrop"])
+@pytest.fixture(autouse=True)
+def _single_thread():
+    """The goldens were produced with one CPU thread; MKL's GEMM blocking (hence the fp32 summation order) depends on
+    the thread count, so bit-exact comparisons pin it."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
+
+
+@pytest.mark.parametrize("name", ["g1_basic_onehot_small", "g1_basic_onehot_e32", "g1_basic_onehot_nodrop",
+                                  "g1_basic_onehot_e64", "g1_basic_onehot_e128", "g1_basic_onehot_e64_h256"])
 def test_basic_onehot_dense_and_table(name):
     state, a, kw = load_golden(name)
     up, ip = a["user_pos"], a["item_pos"]
@@ -42,7 +53,7 @@ def test_mf():
     assert torch.equal(out2, ref)
 
 
-@pytest.mark.parametrize("name", ["g3_att_dense8", "g3_att_none", "g3_att_cos"])
+@pytest.mark.parametrize("name", ["g3_att_dense8", "g3_att_none", "g3_att_cos", "g3_att_vec64", "g3_att_vec128"])
 def test_attention(name):
     state, a, kw = load_golden(name)
     out, att = O.attention_ncf_forward(state, torch.from_numpy(a["candidate_items"]),
@@ -50,6 +61,9 @@ def test_attention(name):
                                        use_cos_sim_instead=kw["use_cos_sim_instead"], return_attention_weights=True)
     assert torch.equal(out, torch.from_numpy(a["out"]))
     assert torch.equal(att, torch.from_numpy(a["att"]))
+    if name.startswith("g3_att_vec"):
+        assert float(att[0].abs().sum()) == 0.0
+        return
     # quirks the fixture was built to exercise (attention_ncf.py:158, :208-209)
     assert float(att[1].abs().sum()) == 0.0          # user with no ratings -> all zeros, not NaN
     assert float(att[2, 3]) == 0.0                   # exact-0 entry is treated as unrated
