@@ -127,6 +127,43 @@ def cpu_baseline(model, seconds=12.0):
                       f"torch CPU fp32, {cores} threads, {dt:.1f} s"}
 
 
+def cpu_baseline_dense_cfg1(iters=60):
+    """the reference-FAITHFUL formulation (dense one-hot rows through nn.Linear, basic_ncf.py:37-42)
+    at the largest size that fits comfortably — BASELINE configs[0]: 6040 x 3706, emb 32, MLP [256], batch 512.
+    (At cfg 2 the dense input alone would be 262 TB.)  Median of `iters` timed forwards after 5 warm-ups."""
+    from oracle import ncf_oracle as O
+    torch.manual_seed(0)
+    Uc, Ic, Ec, Bc = 6040, 3706, 32, 512
+    state = {"user_embeddings.0.weight": torch.randn(Ec, Uc) * 0.01, "user_embeddings.0.bias": torch.zeros(Ec),
+             "item_embeddings.0.weight": torch.randn(Ec, Ic) * 0.01, "item_embeddings.0.bias": torch.zeros(Ec),
+             "MLP.0.weight": torch.randn(256, 2 * Ec) * 0.1, "MLP.0.bias": torch.zeros(256),
+             "MLP.3.weight": torch.randn(1, 256) * 0.1, "MLP.3.bias": torch.zeros(1)}
+    g = torch.Generator().manual_seed(1)
+    xu = torch.nn.functional.one_hot(torch.randint(0, Uc, (Bc,), generator=g), Uc).float()
+    xi = torch.nn.functional.one_hot(torch.randint(0, Ic, (Bc,), generator=g), Ic).float()
+    ts = []
+    with torch.no_grad():
+        for k in range(iters + 5):
+            t0 = time.perf_counter()
+            O.basic_ncf_forward(state, xu, xi)
+            if k >= 5:
+                ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
+    return {"value": Bc / med, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"dense one-hot formulation at cfg-1 scale ({Uc} x {Ic}, emb {Ec}, MLP [256], batch {Bc}), median of {iters} forwards"}
+
+
+def zipf_indices(n_rows, count, alpha, device, seed):
+    """Zipf(alpha) ranks over n_rows ids by inverse-CDF sampling on the device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    w = 1.0 / torch.arange(1, n_rows + 1, device=device, dtype=torch.float64) ** alpha
+    cdf = torch.cumsum(w, 0)
+    u = torch.rand(count, device=device, generator=g, dtype=torch.float64) * cdf[-1]
+    rank = torch.searchsorted(cdf, u).clamp_(max=n_rows - 1)
+    perm = torch.randperm(n_rows, device=device, generator=g)  # popular ids scattered over the table
+    return perm[rank]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +279,28 @@ def main():
     gather_us = e0.elapsed_time(e1) * 1e3 / reps
     gather_gbs = GATHER_BYTES_PER_PAIR * B / (gather_us * 1e-6) / 1e9
 
+    # ---- SURVEY §8d cfg 2 variants: Zipf(1.05) user ids, and the [256]-only MLP (train_model.py:40-42 default) ----
+    def per_launch(fn, n=100):
+        for _ in range(60):  # the chip takes milliseconds to settle its clock after a change of kernel: warm up long enough
+            fn()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
+    zu = zipf_indices(U, B, 1.05, device, 2024)
+    zi = batches[0][1]
+    per_launch(lambda: native.score_fused(tu, batches[2][0], ti, batches[2][1], packed, out=outbuf))  # back to this kernel's clock state
+    zipf_fused_us = per_launch(lambda: native.score_fused(tu, zu, ti, zi, packed, out=outbuf))
+    lin = [m for m in model.MLP if isinstance(m, torch.nn.Linear)]
+    g2 = torch.Generator(device=device).manual_seed(7)
+    w_last = (torch.rand((1, HIDDEN[0]), device=device, generator=g2) * 2 - 1) / HIDDEN[0] ** 0.5
+    packed256 = native.PackedMLP([lin[0].weight, w_last], [lin[0].bias, lin[2].bias])
+    h256_us = per_launch(lambda: native.score_fused(tu, batches[1][0], ti, batches[1][1], packed256, out=outbuf))
+    zipf_gather_us = per_launch(lambda: native.gather_concat(tu, zu, ti, zi, out=gbuf))
+
     if rank == 0:
         dig_f = profile_digest("ncf::score_fused_f32_kernel<128, 256, 128>") or {}
         dig_g = profile_digest("ncf::gather_concat_vec16") or {}
@@ -277,10 +336,19 @@ def main():
                                 "algorithmic_bytes_per_launch": GATHER_BYTES_PER_PAIR * B,
                                 "rocprof_avg_us_isolated": dig_g.get("rocprof_avg_us"), "profile": dig_g.get("profile")},
         }
+        flop256 = 2 * (2 * E * HIDDEN[0] + HIDDEN[0])
+        line["variants"] = {
+            "zipf_1.05_users": {"fused_us_per_launch": zipf_fused_us, "fused_pairs_per_s": B / (zipf_fused_us * 1e-6),
+                                "gather_us_per_launch": zipf_gather_us,
+                                "gather_GBps_algorithmic": GATHER_BYTES_PER_PAIR * B / (zipf_gather_us * 1e-6) / 1e9},
+            "mlp_256_only": {"fused_us_per_launch": h256_us, "fused_pairs_per_s": B / (h256_us * 1e-6),
+                             "flop_per_pair": flop256, "frac_of_fp32_mfma_peak": flop256 * B / (h256_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+        }
         if fold_info is not None:
             line["folded_roofline"] = fold_info
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model)
+            line["cpu_baseline_reference_formulation"] = cpu_baseline_dense_cfg1()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -39,6 +39,9 @@ def main():
     ws = [torch.randn(dims[i + 1], dims[i], device=dev, generator=g) / dims[i] ** 0.5 for i in range(3)]
     bs = [torch.randn(dims[i + 1], device=dev, generator=g) * 0.1 for i in range(3)]
     batches = [(torch.randint(0, U, (Bsz,), device=dev, generator=g), torch.randint(0, I, (Bsz,), device=dev, generator=g)) for _ in range(16)]
+    if os.environ.get("AB_ZIPF"):
+        import bench
+        batches = [(bench.zipf_indices(U, Bsz, float(os.environ["AB_ZIPF"]), dev, 100 + k), b[1]) for k, b in enumerate(batches)]
     d = (ctypes.c_int * 4)(*dims)
     libs = []
     for i, fl in enumerate(variants):
