@@ -151,3 +151,34 @@ def test_attention_and_graph_training_paths_run_on_cpu():
     out = g(gp.get_graph(), users, items, torch.device("cpu"))
     out.sum().backward()
     assert out.shape == (2, 1) and g.gnn_convs[0].user2item_W[0].weight.grad is not None
+
+
+def test_segmented_csr_tree_structure_cpu():
+    """native.SegmentedCSR is pure index plumbing (torch ops) until spmm() is called: its level structure can be checked
+    on CPU.  Level 0 partitions every row's edges into <= seg_len pieces; each further level groups the previous
+    level's partial sums of the still-split rows into <= fan pieces; the last level has exactly one segment per row."""
+    from deeprecommendation_amd.native import SegmentedCSR
+    counts = torch.tensor([0, 3, 1300, 7, 0, 70000, 512, 513])
+    rowptr = torch.zeros(len(counts) + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    E = int(rowptr[-1])
+    csr = SegmentedCSR(rowptr, torch.zeros(E, dtype=torch.int32), None, seg_len=512, fan=8)
+    segptr, row_of, _ = csr.levels[0]
+    assert int(segptr[0]) == 0 and int(segptr[-1]) == E
+    lens = segptr[1:] - segptr[:-1]
+    assert int(lens.max()) <= 512 and bool((lens >= 0).all())
+    per_row = torch.bincount(row_of.long(), weights=lens.double(), minlength=len(counts))
+    assert torch.equal(per_row.long(), counts)                       # every edge in exactly one segment of its row
+    assert torch.equal(torch.bincount(row_of.long(), minlength=len(counts)) >= 1, torch.ones(len(counts), dtype=torch.bool))
+    assert bool((row_of[1:] >= row_of[:-1]).all())                   # a row's segments are consecutive
+    prev_nseg = torch.bincount(row_of.long(), minlength=len(counts))
+    assert len(csr.levels) == 4                                      # 70000 edges: 137 partials -> 18 -> 3 -> 1
+    for segptr, row_of, edge_ids in csr.levels[1:]:
+        lens = segptr[1:] - segptr[:-1]
+        assert int(lens.max()) <= 8
+        rows = torch.unique(row_of.long())
+        assert set(rows.tolist()) == set(torch.nonzero(prev_nseg > 1).flatten().tolist())   # exactly the still-split rows
+        assert int(lens.sum()) == int(edge_ids.numel()) == int(prev_nseg[prev_nseg > 1].sum())
+        assert bool((edge_ids[1:] > edge_ids[:-1]).all())            # partials are consumed in index (= edge) order
+        prev_nseg = torch.bincount(row_of.long(), minlength=len(counts))
+    assert int(prev_nseg.max()) == 1
