@@ -14,6 +14,8 @@
 // Bound at config 5 (E = 128): bf16 MFMA 196 864 FLOP/pair (2.5 PF -> 12.7 G pairs/s) vs HBM 532 B/pair
 // (8 TB/s -> 15 G pairs/s): roughly balanced.
 #include "ncf_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 #ifndef NCF_BF16_X_DEPTH
 #define NCF_BF16_X_DEPTH 4   // gathered-row prefetch ring, in 16-wide k-steps (measured: 4 -> 20.6 us, 8 -> 21.3, 16 -> 21.7)
@@ -77,6 +79,22 @@ __device__ __forceinline__ bf16x8_t pack_relu8(const f32x16& acc, int base) {
         r[j + 1] = p[1];
     }
     return r;
+}
+
+// the same fragment with the ReLU applied AFTER the rounding, on the packed pairs as signed 16-bit integers (a negative
+// bf16 is a negative int16; rounding keeps the sign, so the result is bit-identical): 4 cvt + 4 v_pk_max_i16
+// instead of 16 v_max_f32 + 4 cvt — this matters where the conversion has to hide in MFMA issue gaps
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8_t pack_relu8_int(const f32x16& acc, int base) {
+    union { bf16x8_t b; s16x2_t s[4]; } r;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        f32x2 v = {acc[base + j], acc[base + j + 1]};
+        union { bf16x2_t b; s16x2_t s; } p;
+        p.b = __builtin_convertvector(v, bf16x2_t);
+        r.s[j >> 1] = __builtin_elementwise_max(p.s, (s16x2_t){0, 0});
+    }
+    return r.b;
 }
 
 template <int K0, int N1, int N2>
@@ -295,6 +313,457 @@ __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(
     BF16_STAMP(5);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-stationary persistent form (the default for EA, EB multiples of 64).
+//
+// One 256-thread workgroup per CU, ONE wave per SIMD, looping over 64-pair tiles.  The weights never move again
+// after the prologue: wave w keeps its slice as MFMA A fragments in registers for the whole launch — layer-1 neurons
+// [64w, 64w+64) (2 row tiles x K0/16 k-steps) and layer-2 neurons [32w, 32w+32) (1 row tile x N1/16 k-steps),
+// 192 VGPRs at 256-256-128 — so nothing is streamed from L2 per tile and no weight byte crosses LDS.
+// What crosses LDS instead is the data:
+//   * X: the tile's gathered rows, fetched by LDS-DMA (global_load_lds_dwordx4, per-lane SOURCE address) in pieces of
+//     8 pairs x 128 B — full cache lines — three tiles deep (ring of 3 buffers, 2 tiles = 64 KB in flight per CU
+//     under the MFMAs).  Inside a piece lane position L = (chunk%8)*8 + pair%8, XOR 8 for pair groups 2 and 3:
+//     the B-fragment read of k-step s (lane (m,h) <- 16-byte chunk 2s+h of pair m) is then a conflict-free
+//     ds_read_b128 (each of its 16-lane groups covers 16 distinct bank quads);
+//   * H1: each wave's ReLU'd, bf16-rounded layer-1 slice, written as ready-made layer-2 B fragments (same permuted
+//     k order as the streaming kernel, so W2 keeps its packing) — one barrier, then every wave reads all of it;
+//   * 64 x 4 partial dots of the last layer.
+// Row ids come in by LDS-DMA as well (one dword DMA per wave and tile into the wave's own slot, four tiles ahead) so
+// that no VGPR-destination load sits in the vmcnt queue between the DMAs: the loop's only vector-memory ops are the
+// DMAs and the output store, waited for with a counted s_waitcnt vmcnt before a raw s_barrier (a __syncthreads()
+// would drain the prefetch).
+// Per iteration i: ids DMA(i+4), row DMAs(i+2) -> layer 1(i) -> H1 -> barrier -> layer 2(i) -> partial dots ->
+// wait ids(i+3) + rows(i+1) -> row pointers(i+3) -> barrier -> store out(i).
+#ifndef NCF_BF16_WS
+#define NCF_BF16_WS 1
+#endif
+#ifndef NCF_BF16_WS_MIN_PAIRS
+#define NCF_BF16_WS_MIN_PAIRS 131072
+#endif
+
+#if NCF_BF16_STAMP
+// diagnostic builds: stamps of iterations 0..3 and 100..103 of every workgroup, [block][8 iterations][8 stamps]
+#define WS_STAMP(k) do { if (a.dbg && lane == 0 && w == 0 && (it < 4 || (it >= 100 && it < 104))) \
+    a.dbg[((int64_t)blockIdx.x * 8 + (it < 4 ? it : it - 96)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WS_STAMP(k) do { } while (0)
+#endif
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA by inline asm: the compiler's waitcnt pass treats the builtin form as an out-of-order LGKM event and turns
+// every later `s_waitcnt lgkmcnt(N)` of the kernel into lgkmcnt(0) (measured: ~100 stall cycles per k-step at one wave
+// per SIMD); hidden in asm, its own LDS reads keep their counted waits and the DMAs are counted by hand (vmcnt).
+// M0 (the wave-uniform LDS destination) is saved and restored inside the statement.
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* g, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+
+template <int K0, int N1, int N2>
+struct WsLayout {
+    static constexpr int P = 64, CTN = 2;                 // pairs per tile, 32-pair column tiles per tile
+    static constexpr int NCU = K0 / 64;                   // 128-byte column units of the concatenated row
+    static constexpr int CT_BYTES = NCU * 4 * 1024;       // X image of one column tile
+    static constexpr int XBUF = CTN * CT_BYTES;
+    static constexpr int Q2 = N1 / 16;
+    static constexpr int H1_BYTES = N2 > 0 ? CTN * Q2 * 1024 : 0;
+    static constexpr int LAST = N2 > 0 ? N2 : N1;
+    static constexpr int OFF_H1 = 3 * XBUF;
+    static constexpr int OFF_RED = OFF_H1 + H1_BYTES;     // float red[4][64]
+    static constexpr int OFF_B1 = OFF_RED + 1024;
+    static constexpr int OFF_B2 = OFF_B1 + N1 * 4;
+    static constexpr int OFF_WL = OFF_B2 + (N2 > 0 ? N2 * 4 : 0);
+    static constexpr int OFF_IDS = OFF_WL + LAST * 4;     // int64 ids[4 waves][2 slots][2 ct][2 tables][8]
+    static constexpr int TOTAL = OFF_IDS + 4 * 2 * 256;
+};
+
+#define SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define SGB_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
+#define SGB_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define SGB_DSW(n) __builtin_amdgcn_sched_group_barrier(0x200, n, 0)
+
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }  // one v_med3_f32
+
+template <int K0, int N1, int N2>
+__global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const int64_t* __restrict__ idxA,
+                                                               const int64_t* __restrict__ idxB, float* __restrict__ out,
+                                                               const unsigned char* __restrict__ zeros, int64_t ntiles) {
+    using L = WsLayout<K0, N1, N2>;
+    static_assert(N1 == 256 && (N2 == 0 || N2 == 128), "wave w owns 64 layer-1 and 32 layer-2 neurons");
+    constexpr int Q1 = K0 / 16, Q2 = L::Q2, CTN = L::CTN, NCU = L::NCU;
+    constexpr int ROWS = CTN * NCU;                          // row-DMA pieces per wave and tile
+    static_assert(ROWS <= Q1, "row-DMA pieces are spread over the k-steps of phase A");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[L::TOTAL];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int ncuA = a.EA / 64;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;        // LDS byte address of the array (M0 of the DMAs)
+#if NCF_BF16_STAMP
+    if (a.dbg && lane == 0 && w == 0) a.dbg[256 * 64 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // kernel start
+#endif
+    // DMA lane role inside a piece: pair slot ml = lane & 7 of group w, chunk cl of the 128-byte unit
+    const int cl = ((lane ^ (w >= 2 ? 8 : 0)) >> 3);
+    const int ml = lane & 7;
+    // reader lane offset inside an X column-tile image (k-step s adds (s>>2)*4096 + (s&3)*256)
+    const int g = m >> 3;
+    const unsigned rd_off = g * 1024 + ((h * 128 + (m & 7) * 16) ^ (g >= 2 ? 128 : 0));
+
+    const int64_t stride = gridDim.x;
+    int64_t tile = blockIdx.x;
+    const bool e1 = tile + stride < ntiles, e2 = tile + 2 * stride < ntiles, e3 = tile + 3 * stride < ntiles;
+
+    // ---- prologue.  Oldest first in the vector-memory queue: the ids of tiles 0..2 (they head the longest
+    // dependent chain: ids -> row addresses -> row DMAs -> first MFMA), then the weights (registers for the whole
+    // launch), then the biases (LDS). ----
+    int64_t pid[3][CTN][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct) {
+            const int64_t tt = (t == 0 || (t == 1 && e1) || (t == 2 && e2)) ? tile + t * stride : tile;
+            const int64_t p0 = tt * L::P + 32 * ct + 8 * w + ml;
+            const int64_t p = p0 < a.B ? p0 : a.B - 1;
+            pid[t][ct][0] = idxA[p];
+            pid[t][ct][1] = idxB[p];
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 wa1[2][Q1];
+#pragma unroll
+    for (int s = 0; s < Q1; ++s)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            wa1[nt][s] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp1) + ((size_t)(s * (N1 / 32) + 2 * w + nt) * 64 + lane) * 16);
+    u32x4 wa2[N2 > 0 ? Q2 : 1];
+    if constexpr (N2 > 0) {
+#pragma unroll
+        for (int s = 0; s < Q2; ++s)
+            wa2[s] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp2) + ((size_t)(s * (N2 / 32) + w) * 64 + lane) * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        float* lb1 = reinterpret_cast<float*>(lds + L::OFF_B1);
+        for (int i = threadIdx.x; i < N1; i += 256) lb1[i] = a.b1[i];
+        if constexpr (N2 > 0) {
+            float* lb2 = reinterpret_cast<float*>(lds + L::OFF_B2);
+            for (int i = threadIdx.x; i < N2; i += 256) lb2[i] = a.b2[i];
+        }
+        float* lwl = reinterpret_cast<float*>(lds + L::OFF_WL);
+        for (int i = threadIdx.x; i < L::LAST; i += 256) lwl[i] = a.wl[i];
+    }
+    const float bl = a.bl[0];
+
+    // per-lane source rows of one tile: [ct][table]; an out-of-range id reads the 512-byte zero block instead
+    typedef const unsigned char* RowSrc[CTN][2];
+    bool oob_seen = false;                                   // stored once, after the loop
+    auto resolve = [&](RowSrc& src, int ct, int64_t p0, int64_t ia, int64_t ib) {
+        const bool okA = (ia >= 0) & (ia < a.rowsA);
+        const bool okB = (ncuA == NCU) | ((ib >= 0) & (ib < a.rowsB));
+        oob_seen |= !(okA & okB) & (p0 < a.B);
+        src[ct][0] = (okA ? reinterpret_cast<const unsigned char*>(a.tabA + ia * a.ldA) : zeros) + cl * 16;
+        src[ct][1] = ((okB & (ncuA < NCU)) ? reinterpret_cast<const unsigned char*>(a.tabB + ib * a.ldB) : zeros) + cl * 16;
+    };
+    // steady state: a tile's 32 ids per wave (2 column tiles x 2 tables x 8 pairs) arrive by ONE dword LDS-DMA into
+    // the wave's own 256-byte slot (lane = dword), so that the vmcnt queue holds nothing but DMAs and stores
+    auto ids_dma = [&](int64_t t, int slot) {
+        const int grp = lane >> 4, dw = lane & 15;
+        const int64_t p0 = t * L::P + 32 * (grp >> 1) + 8 * w + (dw >> 1);
+        const int64_t p = p0 < a.B ? p0 : a.B - 1;
+        const int* gp = reinterpret_cast<const int*>(((grp & 1) ? idxB : idxA) + p) + (dw & 1);
+        dma4(gp, lds0 + L::OFF_IDS + (w * 2 + slot) * 256);
+    };
+    auto locate_lds = [&](RowSrc& src, int64_t t, int slot) {
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct) {
+            const unsigned char* q = lds + L::OFF_IDS + (w * 2 + slot) * 256 + ct * 128 + ml * 8;
+            const int64_t ia = *reinterpret_cast<const int64_t*>(q);
+            const int64_t ib = *reinterpret_cast<const int64_t*>(q + 64);
+            resolve(src, ct, t * L::P + 32 * ct + 8 * w + ml, ia, ib);
+        }
+    };
+    // one 1-KiB piece (8 pairs x 128 B) of a tile's X image: column tile ct, 128-byte unit cu, pair group w
+    auto issue_piece = [&](const RowSrc& src, int buf, int ct, int cu) {
+        const bool fromA = cu < ncuA;
+        const unsigned char* gp = (fromA ? src[ct][0] : src[ct][1]) + (fromA ? cu : cu - ncuA) * 128;
+        if (NCF_BF16_ABLATE == 1) return;                        // diagnostics: no row DMAs
+        if (NCF_BF16_ABLATE == 3) gp = reinterpret_cast<const unsigned char*>(a.tabA) + ((gp - reinterpret_cast<const unsigned char*>(a.tabA)) & 0xFFFFF);  // diagnostics: rows from a 1 MiB window
+        dma16(gp, lds0 + buf * L::XBUF + ct * L::CT_BYTES + (cu * 4 + w) * 1024);
+    };
+
+    // vector-memory queue of a wave from here on, oldest first (rows = ROWS DMAs; a missing tile's entries are absent):
+    //   ids(3) rows(0) rows(1) | ids(4) rows(2) | ids(5) rows(3) [out(0)] | ids(6) rows(4) [out(1)] | ...
+    // In iteration `it` the wave needs ids(it+3) and rows(it+1): everything except the entries of its own phase A.
+    RowSrc src;
+    {
+        RowSrc src0, src1;
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct) {
+            resolve(src0, ct, tile * L::P + 32 * ct + 8 * w + ml, pid[0][ct][0], pid[0][ct][1]);
+            resolve(src1, ct, (tile + stride) * L::P + 32 * ct + 8 * w + ml, pid[1][ct][0], pid[1][ct][1]);
+            resolve(src, ct, (tile + 2 * stride) * L::P + 32 * ct + 8 * w + ml, pid[2][ct][0], pid[2][ct][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (e3) ids_dma(tile + 3 * stride, 1);
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct)
+#pragma unroll
+            for (int cu = 0; cu < NCU; ++cu) issue_piece(src0, 0, ct, cu);
+        if (e1) {
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct)
+#pragma unroll
+                for (int cu = 0; cu < NCU; ++cu) issue_piece(src1, 1, ct, cu);
+        }
+    }
+    // the weights are older than every DMA: using them here lets hipcc retire its own waits for them now instead of
+    // re-emitting `s_waitcnt vmcnt(47..0)` through the first iteration (it cannot see the DMAs, so those would drain them)
+#pragma unroll
+    for (int s = 0; s < Q1; ++s) asm volatile("" ::"v"(wa1[0][s]), "v"(wa1[1][s]));
+    if constexpr (N2 > 0) {
+#pragma unroll
+        for (int s = 0; s < Q2; ++s) asm volatile("" ::"v"(wa2[s]));
+    }
+    if (e1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // Steady state.  A wave alone on its SIMD has nobody to cover its non-MFMA work, so each tile is run as a pipeline
+    // over its two column tiles and every VALU / LDS / DMA piece is placed under MFMAs of the OTHER column tile:
+    //   A: layer 1 (ct0) | row DMAs of tile it+2, ids DMA of tile it+4; last-layer dot of ct1 of tile it-1 -> LDS
+    //   B: layer 1 (ct1) | ReLU + bf16 + H1 write of ct0                          -> barrier alpha
+    //   C: layer 2 (ct0) | ReLU + bf16 + H1 write of ct1; out(it-1); wait rows(it+1) -> barrier beta
+    //   D: layer 2 (ct1) | last-layer dot of ct0, row pointers of tile it+3
+    // B fragments come through register rings read 3 (layer 1, 64 MFMA cycles per fragment) or AHEAD2 (layer 2, 32)
+    // fragments ahead; sched_group_barrier sequences spread the fillers over the MFMA issue gaps.
+#ifndef NCF_WS_AHEAD2
+#define NCF_WS_AHEAD2 6
+#endif
+    constexpr int RING = 4, AHEAD = 3;
+    constexpr int AHEAD2 = NCF_WS_AHEAD2, RING2 = AHEAD2 + 2;
+    float* const red = reinterpret_cast<float*>(lds + L::OFF_RED);
+    constexpr int NPREV = N2 > 0 ? 1 : 2;                    // accumulator tiles of ct1 whose last-layer dot is deferred
+    // The accumulators live across iterations: ct1's last hidden layer (acc2[1], or acc1[.][1] without a second
+    // layer) is consumed in the NEXT iteration's phase A, before that iteration re-initialises it.
+    f32x16 acc1[2][CTN];
+    f32x16 acc2[N2 > 0 ? CTN : 1];
+    auto prev1 = [&](int i) -> const f32x16& { if constexpr (N2 > 0) return acc2[1]; else return acc1[i][1]; };
+    float prev0 = 0.f;                                       // ct0's finished partial dot of the previous tile
+    auto dot_quarter = [&](const f32x16& acc, int neuron0, int gq, float part) {
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(lds + L::OFF_WL + (neuron0 + 8 * gq + 4 * h) * 4);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) part = fmaf(ww[jj], relu1(acc[4 * gq + jj]), part);
+        return part;
+    };
+    auto publish = [&](float p0, float p1) {                 // this wave's share of 64 last-layer dots -> LDS
+        const float v0 = p0 + __shfl_xor(p0, 32), v1 = p1 + __shfl_xor(p1, 32);
+        if (h == 0) { red[w * 64 + m] = v0; red[w * 64 + 32 + m] = v1; }
+    };
+    auto store_out = [&](int64_t t) {                        // after the barrier that follows publish(): wave 0
+        if (w == 0) {
+            const int64_t p = t * L::P + lane;
+            const float v = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane] + bl;
+            if (p < a.B) out[p] = v;
+        }
+    };
+
+    // accumulator tiles start as their bias, read from LDS straight into the accumulator registers
+    auto bias_tile = [&](int off, int neuron0) {
+        f32x16 t;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(lds + off + (neuron0 + 8 * gq + 4 * h) * 4);
+            t[4 * gq + 0] = bb[0]; t[4 * gq + 1] = bb[1]; t[4 * gq + 2] = bb[2]; t[4 * gq + 3] = bb[3];
+        }
+        return t;
+    };
+    // The barriers are straddled: the last TAIL k-steps of the MFMA stream that precedes a barrier are issued AFTER
+    // it, so that they cover the LDS latency of the first fragment reads of the stream that follows it (those reads
+    // cannot be issued before the barrier).  The X ring and the bias tiles of the next tile are likewise requested
+    // inside the previous tile's last k-steps (its rows are visible since beta).
+    constexpr int TAIL = 4;
+    constexpr int BODY1 = Q1 - TAIL, BODY2 = Q2 - TAIL;
+    static_assert(BODY1 % 4 == 0 && BODY2 % 4 == 0, "four fragments are spread over the body k-steps");
+    auto xaddr = [&](int b, int j) {
+        return lds + b * L::XBUF + rd_off + (j / Q1) * L::CT_BYTES + ((j % Q1) >> 2) * 4096 + ((j % Q1) & 3) * 256;
+    };
+    u32x4 xf[RING];
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) xf[j] = *reinterpret_cast<const u32x4*>(xaddr(0, j));
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc1[nt][0] = bias_tile(L::OFF_B1, 64 * w + 32 * nt);
+    const unsigned char* hbase = lds + L::OFF_H1 + lane * 16;
+
+    for (int it = 0; tile < ntiles; ++it, tile += stride) {
+        const int buf = it % 3, nbuf = (it + 1) % 3;
+        WS_STAMP(0);
+#if NCF_BF16_STAMP
+        if (a.dbg && lane == 0 && w == 0 && (it < 4 || (it >= 100 && it < 104)))
+            a.dbg[((int64_t)blockIdx.x * 8 + (it < 4 ? it : it - 96)) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
+        const bool has2 = tile + 2 * stride < ntiles, has3 = tile + 3 * stride < ntiles, has4 = tile + 4 * stride < ntiles;
+        if (has4) ids_dma(tile + 4 * stride, it & 1);       // slot (it+4)&1; slot (it+3)&1 is read in phase D
+        float part1 = 0.f;                                   // deferred dot of the previous tile's ct1
+        float part0 = 0.f;                                   // this tile's ct0
+        u32x4 hf[CTN][N2 > 0 ? RING2 : 1];
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- layer 1: 2*Q1 fragment steps, column tile ct = j / Q1 ----------------
+#pragma unroll
+        for (int j = 0; j < CTN * Q1; ++j) {
+            const int ct = j / Q1, s = j % Q1;
+            if (j + AHEAD < CTN * Q1) xf[(j + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(xaddr(buf, j + AHEAD));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                acc1[nt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa1[nt][s]), as_bf16x8(xf[j % RING]), acc1[nt][ct], 0, 0, 0);
+            if (ct == 0) {
+                // phase A fillers: one row-DMA piece per k-step, then the previous tile's ct1 dot in quarters
+                if (s < ROWS) {
+                    if (has2) issue_piece(src, (it + 2) % 3, s / NCU, s % NCU);
+                } else if (it > 0) {
+                    constexpr int DQ = 4 * NPREV;            // dot quarters to place
+                    const int k = s - ROWS;
+                    constexpr int PER = (DQ + (Q1 - ROWS) - 2) / ((Q1 - ROWS) - 1);   // quarters per remaining step but the last
+                    if (s < Q1 - 1) {
+#pragma unroll
+                        for (int d = k * PER; d < (k + 1) * PER && d < DQ; ++d)
+                            part1 = dot_quarter(prev1(d / 4), (N2 > 0 ? 32 * w : 64 * w + 32 * (d / 4)), d % 4, part1);
+                    } else {
+                        publish(prev0, part1);
+                    }
+                }
+                if (s == Q1 - 2) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc1[nt][1] = bias_tile(L::OFF_B1, 64 * w + 32 * nt);
+                }
+                SGB_DSR(1); SGB_MFMA(1); SGB_VALU(4); SGB_MFMA(1); SGB_VALU(4);
+                if (s == Q1 - 1) WS_STAMP(1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (N2 > 0) {
+                // phase B fillers: ct0's four finished fragments over the BODY1 k-steps before alpha
+                if (s < BODY1 && (s + 1) % (BODY1 / 4) == 0) {
+                    const int f = (s + 1) / (BODY1 / 4) - 1, nt = f >> 1, s2 = f & 1;
+                    const bf16x8_t hb = pack_relu8_int(acc1[nt][0], 8 * s2);
+                    *reinterpret_cast<bf16x8_t*>(lds + L::OFF_H1 + (0 * Q2 + 2 * (2 * w + nt) + s2) * 1024 + lane * 16) = hb;
+#pragma unroll
+                    for (int r = 0; r < BODY1 / 4; ++r) { SGB_DSR(1); SGB_MFMA(1); SGB_VALU(8 / (BODY1 / 4)); SGB_MFMA(1); SGB_VALU(8 / (BODY1 / 4)); }
+                    SGB_DSW(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (s == BODY1 - 1) {
+                    WS_STAMP(2);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();            // alpha: H1(ct0) and the previous tile's dots are visible
+                    WS_STAMP(3);
+#pragma unroll
+                    for (int q = 0; q < AHEAD2; ++q) hf[0][q] = *reinterpret_cast<const u32x4*>(hbase + (0 * Q2 + q) * 1024);
+                    acc2[0] = bias_tile(L::OFF_B2, 32 * w);
+                    if (it > 0) store_out(tile - stride);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (s >= BODY1) __builtin_amdgcn_sched_barrier(0);
+            } else {
+                // no second layer: ct0's last-layer dot, a quarter of the k-steps per accumulator half
+                if ((s + 1) % (Q1 / 4) == 0) {
+                    const int f = (s + 1) / (Q1 / 4) - 1, nt = f >> 1, s2 = f & 1;
+                    part0 = dot_quarter(acc1[nt][0], 64 * w + 32 * nt, 2 * s2, part0);
+                    part0 = dot_quarter(acc1[nt][0], 64 * w + 32 * nt, 2 * s2 + 1, part0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if constexpr (N2 > 0) {
+            // ---------------- layer 2 ----------------
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct) {
+                if (ct == 1 && has3) locate_lds(src, tile + 3 * stride, (it + 1) & 1);   // overwrites src[][] (rows(it+2) are issued)
+#pragma unroll
+                for (int q = 0; q < Q2; ++q) {
+                    if (q + AHEAD2 < Q2) hf[ct][(q + AHEAD2) % RING2] = *reinterpret_cast<const u32x4*>(hbase + (ct * Q2 + q + AHEAD2) * 1024);
+                    acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa2[q]), as_bf16x8(hf[ct][q % RING2]), acc2[ct], 0, 0, 0);
+                    if (q < BODY2 && (q + 1) % (BODY2 / 4) == 0) {
+                        const int f = (q + 1) / (BODY2 / 4) - 1;
+                        if (ct == 0) {
+                            // phase C filler: one finished ct1 fragment of layer 1 per quarter of the body
+                            const int nt = f >> 1, s2 = f & 1;
+                            const bf16x8_t hb = pack_relu8_int(acc1[nt][1], 8 * s2);
+                            *reinterpret_cast<bf16x8_t*>(lds + L::OFF_H1 + (1 * Q2 + 2 * (2 * w + nt) + s2) * 1024 + lane * 16) = hb;
+                        } else {
+                            // phase D filler: a quarter of ct0's last-layer dot per quarter of the body
+                            part0 = dot_quarter(acc2[0], 32 * w, f, part0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < BODY2 / 4; ++r) { SGB_DSR(1); SGB_MFMA(1); SGB_VALU(16 / (BODY2 / 4)); }
+                        if (ct == 0) SGB_DSW(1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (q == BODY2 - 1) {
+                        if (ct == 0) {
+                            // this wave's pieces of rows(it+1) (and ids(it+3)) have landed once only this iteration's DMAs are left
+                            if (has4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS + 1) : "memory");
+                            else if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();    // beta: H1(ct1) and rows(it+1) are visible
+                            WS_STAMP(4);
+#pragma unroll
+                            for (int qq = 0; qq < AHEAD2; ++qq) hf[1][qq] = *reinterpret_cast<const u32x4*>(hbase + (1 * Q2 + qq) * 1024);
+                            acc2[1] = bias_tile(L::OFF_B2, 32 * w);
+                        } else {
+                            // the next tile's first fragments and bias tiles (harmless if there is no next tile)
+#pragma unroll
+                            for (int j = 0; j < AHEAD; ++j) xf[j] = *reinterpret_cast<const u32x4*>(xaddr(nbuf, j));
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt) acc1[nt][0] = bias_tile(L::OFF_B1, 64 * w + 32 * nt);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (q >= BODY2) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            WS_STAMP(5);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // alpha: the previous tile's dots are visible
+            if (it > 0) store_out(tile - stride);
+            if (has4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS + 1) : "memory");
+            else if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (has3) locate_lds(src, tile + 3 * stride, (it + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // beta: rows(it+1) are visible; wave 0 is done with the dots
+#pragma unroll
+            for (int j = 0; j < AHEAD; ++j) xf[j] = *reinterpret_cast<const u32x4*>(xaddr(nbuf, j));
+            // ct1's accumulators still hold the hidden layer the next iteration's phase A reads: only ct0's restart here
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc1[nt][0] = bias_tile(L::OFF_B1, 64 * w + 32 * nt);
+            WS_STAMP(5);
+        }
+        prev0 = part0;
+        WS_STAMP(6);
+    }
+    if (oob_seen && a.oob) *a.oob = 1;
+    // the last tile's deferred dot and output
+    if (blockIdx.x < ntiles) {
+        float part1 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4 * NPREV; ++d)
+            part1 = dot_quarter(prev1(d / 4), (N2 > 0 ? 32 * w : 64 * w + 32 * (d / 4)), d % 4, part1);
+        publish(prev0, part1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        store_out(tile - stride);
+    }
+}
+
 // Wp[q][nt][lane][8] (bf16, RNE from fp32) with
 //   natural order   (layer 1): element j = W[32nt + (lane&31)][16q + 8(lane>>5) + j]
 //   permuted order  (layer 2): element j = W[32nt + (lane&31)][32(q>>1) + 16(q&1) + 8(j>>2) + 4(lane>>5) + (j&3)]
@@ -320,7 +789,7 @@ __global__ void copy_or_zero_f32_kernel(const float* __restrict__ src, int n, fl
 }
 
 struct Bf16Blob {
-    size_t wp1, b1, wp2, b2, wl, bl, total;  // byte offsets
+    size_t wp1, b1, wp2, b2, wl, bl, zeros, total;  // byte offsets
 };
 static Bf16Blob bf16_blob(const int* dims, int n_layers) {
     Bf16Blob L{};
@@ -337,6 +806,7 @@ static Bf16Blob bf16_blob(const int* dims, int n_layers) {
     }
     L.wl = off; off += last * 4;
     L.bl = off; off += 16;
+    L.zeros = off; off += 512;  // source of the rows of out-of-range ids (weight-stationary kernel: 4 x 128-byte units)
     L.total = off;
     return L;
 }
@@ -347,11 +817,32 @@ static void launch_bf16(const Bf16Args& a, hipStream_t s) {
     hipLaunchKernelGGL((score_fused_bf16_kernel<K0, N1, N2>), dim3((unsigned)((tiles + NCF_BF16_WGW - 1) / NCF_BF16_WGW)), dim3(NCF_BF16_WGW * 64), 0, s, a);
 }
 
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int K0, int N1, int N2>
+static void launch_ws_bf16(const Bf16Args& a, const unsigned char* zeros, hipStream_t s) {
+    const int64_t ntiles = (a.B + 63) / 64;
+    const int64_t grid = ntiles < num_cus() ? ntiles : num_cus();
+    hipLaunchKernelGGL((score_ws_bf16_kernel<K0, N1, N2>), dim3((unsigned)grid), dim3(256), 0, s, a, a.idxA, a.idxB, a.out, zeros, ntiles);
+}
+
 #define NCF_BF16_INSTANCES(X) X(256, 256, 128) X(256, 256, 0) X(128, 256, 128) X(128, 256, 0)
 
-static bool bf16_dispatch(int K0, int N1, int N2, const Bf16Args* a, hipStream_t s) {
+static bool bf16_dispatch(int K0, int N1, int N2, const Bf16Args* a, const unsigned char* zeros, bool ws, hipStream_t s) {
 #define X(k, n1, n2) \
-    if (K0 == k && N1 == n1 && N2 == n2) { if (a) launch_bf16<k, n1, n2>(*a, s); return true; }
+    if (K0 == k && N1 == n1 && N2 == n2) { \
+        if (a) { if (ws) launch_ws_bf16<k, n1, n2>(*a, zeros, s); else launch_bf16<k, n1, n2>(*a, s); } \
+        return true; \
+    }
     NCF_BF16_INSTANCES(X)
 #undef X
     return false;
@@ -360,7 +851,7 @@ static bool bf16_dispatch(int K0, int N1, int N2, const Bf16Args* a, hipStream_t
 bool bf16_shape_ok(int EA, int EB, int n_layers, const int* dims) {
     if (!dims || (n_layers != 2 && n_layers != 3) || dims[n_layers] != 1) return false;
     if (EA <= 0 || EB < 0 || EA % 16 || EB % 16 || EA + EB != dims[0]) return false;
-    return bf16_dispatch(dims[0], dims[1], n_layers == 3 ? dims[2] : 0, nullptr, nullptr);
+    return bf16_dispatch(dims[0], dims[1], n_layers == 3 ? dims[2] : 0, nullptr, nullptr, false, nullptr);
 }
 
 size_t bf16_packed_bytes(int n_layers, const int* dims) {
@@ -388,6 +879,7 @@ int bf16_pack(int n_layers, const int* dims, const void* const* W, const void* c
     }
     hipLaunchKernelGGL(copy_or_zero_f32_kernel, dim3((last + 255) / 256), dim3(256), 0, s, (const float*)W[n_layers - 1], last, (float*)(P + L.wl));
     hipLaunchKernelGGL(copy_or_zero_f32_kernel, dim3(1), dim3(256), 0, s, bias(n_layers - 1), 1, (float*)(P + L.bl));
+    hipLaunchKernelGGL(copy_or_zero_f32_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, 128, (float*)(P + L.zeros));
     return check_launch("ncf_mlp_pack(bf16)");
 }
 
@@ -410,7 +902,19 @@ int bf16_score(const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, i
 #if NCF_BF16_STAMP
     a.dbg = g_bf16_dbg;
 #endif
-    bf16_dispatch(dims[0], dims[1], n_layers == 3 ? dims[2] : 0, &a, s);
+    // Weight-stationary persistent kernel for large batches whose row widths are whole 128-byte units, else the
+    // slab-streaming one.  Measured crossover (E = 128, 256-256-128-1): 65 536 pairs 21 us vs 19.7 us (its prologue —
+    // ids, then rows, then weights into registers — is 6 us for 4 tiles per workgroup); 262 144 pairs and up 19-28 %
+    // faster.  NCF_BF16_KERNEL=ws|stream in the environment overrides the choice (tests use it to run the edge-case
+    // batches through both).
+    bool ws = NCF_BF16_WS && B >= NCF_BF16_WS_MIN_PAIRS;
+    if (const char* force = getenv("NCF_BF16_KERNEL")) {
+        if (!strcmp(force, "ws")) ws = true;
+        else if (!strcmp(force, "stream")) ws = false;
+    }
+    ws = ws && EA % 64 == 0 && EB % 64 == 0 && idxA && (EB == 0 || idxB);
+    if (ws && !idxB) a.idxB = idxA;   // single table: the id DMA's table-B lanes fetch valid (unused) words
+    bf16_dispatch(dims[0], dims[1], n_layers == 3 ? dims[2] : 0, &a, (const unsigned char*)(P + L.zeros), ws, s);
     return check_launch("ncf_score_fused(bf16)");
 }
 

@@ -247,14 +247,23 @@ def test_full_size_cfg2_properties(native, gpu):
 
 # ----------------------------------------------------------------------------- bf16 fused path (BASELINE config 5 arithmetic)
 @pytest.mark.parametrize("E,hidden", [(128, [256, 128]), (128, [256]), (64, [256, 128]), (64, [256])])
-@pytest.mark.parametrize("B", [1, 255, 256, 257, 3000])
-def test_score_fused_bf16_vs_oracle(gpu, E, hidden, B):
+@pytest.mark.parametrize("B", [1, 63, 255, 256, 257, 3000, 40000, 100001, 140000])
+@pytest.mark.parametrize("kernel", ["stream", "ws", "auto"])
+def test_score_fused_bf16_vs_oracle(gpu, monkeypatch, E, hidden, B, kernel):
     """bf16 tables / weights, fp32 accumulate: gathers are bit-exact on the bf16 table; the MLP is compared with the
     oracle evaluated on the same bf16-rounded operands — tolerance 2e-3 relative (builder-defined: BASELINE pins only
     fp32; the residual is fp32 accumulation order plus bf16 re-rounding of hidden activations that sit on a rounding
-    boundary)."""
+    boundary).  Both bf16 kernels (slab-streaming and weight-stationary persistent) run every batch size, including the
+    ones the library's own dispatch would hand to the other kernel: 40 000 / 100 001 / 140 000 pairs give the
+    persistent kernel 3-9 tiles per workgroup with ragged tails."""
     from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
     from deeprecommendation_amd import native
+    if kernel == "auto":
+        monkeypatch.delenv("NCF_BF16_KERNEL", raising=False)
+        if B not in (3000, 140000):
+            pytest.skip("auto dispatch is covered by one batch on each side of the threshold")
+    else:
+        monkeypatch.setenv("NCF_BF16_KERNEL", kernel)
     torch.manual_seed(E + len(hidden))
     U, I = 3000, 700
     m = BasicNCF(item_dim=I, user_dim=U, item_emb=E, user_emb=E, mlp_dense_layers=hidden).eval()
@@ -274,8 +283,10 @@ def test_score_fused_bf16_vs_oracle(gpu, E, hidden, B):
     assert torch.equal(native.gather_concat(tu, u.to(gpu)), tu[u.to(gpu)])
 
 
-def test_score_fused_bf16_exact_small_integers(native, gpu):
+@pytest.mark.parametrize("kernel", ["stream", "ws"])
+def test_score_fused_bf16_exact_small_integers(native, gpu, monkeypatch, kernel):
     """Exact check of the packed layer-2 k permutation: small integer data is exact in bf16 x bf16 -> fp32."""
+    monkeypatch.setenv("NCF_BF16_KERNEL", kernel)
     E = 64
     dims = [128, 256, 128, 1]
     B = 300
@@ -294,8 +305,10 @@ def test_score_fused_bf16_exact_small_integers(native, gpu):
     assert torch.equal(out.cpu().double(), ref)
 
 
-def test_score_fused_out_of_range_rows_read_as_zeros(native, gpu):
+@pytest.mark.parametrize("kernel", ["stream", "ws"])
+def test_score_fused_out_of_range_rows_read_as_zeros(native, gpu, monkeypatch, kernel):
     """ABI contract: an out-of-range id never faults; that table's part of the row is zeros and the sticky flag is set."""
+    monkeypatch.setenv("NCF_BF16_KERNEL", kernel)
     g = torch.Generator().manual_seed(0)
     E, dims = 64, [128, 256, 128, 1]
     ta = torch.randn(100, E, generator=g)

@@ -25,7 +25,7 @@ def build_variant(i, flags):
 def main():
     variants = sys.argv[1:] or [""]
     dev = torch.device("cuda:0")
-    U, I, E, Bsz = 4_000_000, 1_000_000, 128, 65536
+    U, I, E, Bsz = 4_000_000, 1_000_000, 128, int(os.environ.get("AB_B", 65536))
     g = torch.Generator(device=dev).manual_seed(1)
     tu = (torch.randn(U, E, device=dev, generator=g) * 0.05).to(torch.bfloat16)
     ti = (torch.randn(I, E, device=dev, generator=g) * 0.05).to(torch.bfloat16)
@@ -77,19 +77,41 @@ def main():
     for vi, fl in enumerate(variants):
         if "NCF_BF16_STAMP=1" in fl:
             lib, blob = libs[vi]
-            ntiles = Bsz // 32
-            dbg = torch.zeros(ntiles * 8, dtype=torch.int64, device=dev)
+            ws = "NCF_BF16_WS=0" not in fl
+            ntiles = 256 * 8 if ws else Bsz // 32
+            dbg = torch.zeros(ntiles * 8 + 256, dtype=torch.int64, device=dev)
             lib.ncf_dev_set_bf16_debug_buffer.argtypes = [ctypes.c_void_p]
             lib.ncf_dev_set_bf16_debug_buffer(dbg.data_ptr())
             for k in range(10):
                 run(lib, blob, k)
             torch.cuda.synchronize()
-            dd = dbg.view(ntiles, 8).cpu().double() / 100.0  # us (100 MHz realtime counter)
-            t0 = dd[:, 0].min()
-            names = ["start", "after prologue barrier", "after layer 1", "after pack", "after layer 2", "end"]
-            for i, nme in enumerate(names):
-                col = dd[:, i] - t0
-                print(f"    {nme:24s}: median {col.median().item():6.2f} us  min {col.min().item():6.2f}  max {col.max().item():6.2f}")
+            dd = dbg[:ntiles * 8].view(ntiles, 8).cpu().double() / 100.0  # us (100 MHz realtime counter)
+            if ws:
+                d3 = dd.view(256, 8, 8)
+                start = dbg[ntiles * 8:].cpu().double() / 100.0
+                names = ["top", "A (L1 ct0)", "B (L1 ct1|pack0)", "alpha", "C (L2 ct0|pack1)+beta", "D (L2 ct1|dot0)", "E (dot1, red)"]
+                raw = dbg[:ntiles * 8].view(256, 8, 8).cpu()
+                for a_, b_ in ((0, 3), (4, 7)):
+                    if int(raw[:, b_, 0].max()) > 0:
+                        dc = (raw[:, b_, 7] - raw[:, a_, 7]).double()
+                        dt = (raw[:, b_, 0] - raw[:, a_, 0]).double()
+                        ok = dt > 0
+                        print(f"    in-kernel clock over iterations {a_ if a_ < 4 else a_ + 96}..{b_ if b_ < 4 else b_ + 96}: "
+                              f"{(dc[ok] / dt[ok] * 100).median().item():.0f} MHz")
+                for slot in range(8):
+                    if float(d3[:, slot, 0].max()) == 0:
+                        continue
+                    row = d3[:, slot, :]
+                    rel = row[:, :7] - start[:, None]
+                    seg = rel[:, 1:7] - rel[:, 0:6]
+                    print(f"    iteration {slot if slot < 4 else slot + 96}: top at {rel[:, 0].median().item():7.2f} us after start; "
+                          + "  ".join(f"{n} +{seg[:, i].median().item():.2f}" for i, n in enumerate(names[1:])))
+            else:
+                t0 = dd[:, 0].min()
+                names = ["start", "after prologue barrier", "after layer 1", "after pack", "after layer 2", "end"]
+                for i, nme in enumerate(names):
+                    col = dd[:, i] - t0
+                    print(f"    {nme:24s}: median {col.median().item():6.2f} us  min {col.min().item():6.2f}  max {col.max().item():6.2f}")
         t = sorted(times[vi])
         med = t[len(t) // 2]
         print(f"variant {vi} [{fl or 'default'}]: median {med:.2f} us  min {t[0]:.2f} us  -> {196864*Bsz/med/1e6:.0f} TFLOP/s, {532*Bsz/med/1e3:.0f} GB/s")
