@@ -300,6 +300,20 @@ def main():
     packed256 = native.PackedMLP([lin[0].weight, w_last], [lin[0].bias, lin[2].bias])
     h256_us = per_launch(lambda: native.score_fused(tu, batches[1][0], ti, batches[1][1], packed256, out=outbuf))
     zipf_gather_us = per_launch(lambda: native.gather_concat(tu, zu, ti, zi, out=gbuf))
+    # opt-in variant (BasicNCF.set_fold_first_layer): layer 1 folded into 256-wide tables; reported beside the default
+    # line, never as `value` (its results agree with the oracle to 1e-5 but are not bit-identical to the default kernel's)
+    fold_variant = None
+    if fold_info is None and native.folded_supported(HIDDEN[0], HIDDEN[1]):
+        try:
+            PAv, PBv, tailv = model._folded(tu, ti, "MLP")
+            fv_us = per_launch(lambda: native.score_folded(PAv, batches[1][0], PBv, batches[1][1], tailv, out=outbuf))
+            fold_variant = {"fused_us_per_launch": fv_us, "fused_pairs_per_s": B / (fv_us * 1e-6),
+                            "executed_flop_per_pair": 2 * (HIDDEN[0] * HIDDEN[1] + HIDDEN[1]),
+                            "bytes_per_pair": 2 * HIDDEN[0] * 4 + 2 * 8 + 4,
+                            "table_bytes": int(PAv.numel() + PBv.numel()) * 4}
+            del PAv, PBv
+        except Exception as exc:  # the variant must never take the default line down
+            fold_variant = {"error": str(exc)}
 
     if rank == 0:
         dig_f = profile_digest("ncf::score_fused_f32_kernel<128, 256, 128>") or {}
@@ -344,6 +358,8 @@ def main():
             "mlp_256_only": {"fused_us_per_launch": h256_us, "fused_pairs_per_s": B / (h256_us * 1e-6),
                              "flop_per_pair": flop256, "frac_of_fp32_mfma_peak": flop256 * B / (h256_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS},
         }
+        if fold_variant is not None:
+            line["variants"]["folded_first_layer_opt_in"] = fold_variant
         if fold_info is not None:
             line["folded_roofline"] = fold_info
         if world == 1 and not args.no_cpu_baseline:

@@ -30,7 +30,8 @@
 #define NCF_BF16_STAMP 0     // diagnostic builds only (tools/ab_bf16.py): phase stamps written behind the outputs
 #endif
 #ifndef NCF_BF16_ABLATE
-#define NCF_BF16_ABLATE 0    // diagnostics: 1 = no gathered-row loads, 2 = no weight slab copies / barriers
+#define NCF_BF16_ABLATE 0    // diagnostics: 1 = no gathered-row loads, 2 = no weight slab copies / barriers, 3 = rows from a 1 MiB window,
+                             // 5 = weight-stationary kernel reduced to its ds_read + MFMA + barrier skeleton
 #endif
 
 namespace ncf {
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
     auto issue_piece = [&](const RowSrc& src, int buf, int ct, int cu) {
         const bool fromA = cu < ncuA;
         const unsigned char* gp = (fromA ? src[ct][0] : src[ct][1]) + (fromA ? cu : cu - ncuA) * 128;
-        if (NCF_BF16_ABLATE == 1) return;                        // diagnostics: no row DMAs
+        if (NCF_BF16_ABLATE == 1 || NCF_BF16_ABLATE == 5) return;  // diagnostics: no row DMAs
         if (NCF_BF16_ABLATE == 3) gp = reinterpret_cast<const unsigned char*>(a.tabA) + ((gp - reinterpret_cast<const unsigned char*>(a.tabA)) & 0xFFFFF);  // diagnostics: rows from a 1 MiB window
         dma16(gp, lds0 + buf * L::XBUF + ct * L::CT_BYTES + (cu * 4 + w) * 1024);
     };
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
             a.dbg[((int64_t)blockIdx.x * 8 + (it < 4 ? it : it - 96)) * 8 + 7] = __builtin_amdgcn_s_memtime();
 #endif
         const bool has2 = tile + 2 * stride < ntiles, has3 = tile + 3 * stride < ntiles, has4 = tile + 4 * stride < ntiles;
-        if (has4) ids_dma(tile + 4 * stride, it & 1);       // slot (it+4)&1; slot (it+3)&1 is read in phase D
+        if (has4 && NCF_BF16_ABLATE != 5) ids_dma(tile + 4 * stride, it & 1);   // slot (it+4)&1; slot (it+3)&1 is read in phase D
         float part1 = 0.f;                                   // deferred dot of the previous tile's ct1
         float part0 = 0.f;                                   // this tile's ct0
         u32x4 hf[CTN][N2 > 0 ? RING2 : 1];
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
                 // phase A fillers: one row-DMA piece per k-step, then the previous tile's ct1 dot in quarters
                 if (s < ROWS) {
                     if (has2) issue_piece(src, (it + 2) % 3, s / NCU, s % NCU);
-                } else if (it > 0) {
+                } else if (it > 0 && NCF_BF16_ABLATE != 5) {
                     constexpr int DQ = 4 * NPREV;            // dot quarters to place
                     const int k = s - ROWS;
                     constexpr int PER = (DQ + (Q1 - ROWS) - 2) / ((Q1 - ROWS) - 1);   // quarters per remaining step but the last
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
                 // phase B fillers: ct0's four finished fragments over the BODY1 k-steps before alpha
                 if (s < BODY1 && (s + 1) % (BODY1 / 4) == 0) {
                     const int f = (s + 1) / (BODY1 / 4) - 1, nt = f >> 1, s2 = f & 1;
-                    const bf16x8_t hb = pack_relu8_int(acc1[nt][0], 8 * s2);
+                    const bf16x8_t hb = NCF_BF16_ABLATE == 5 ? as_bf16x8(xf[0]) : pack_relu8_int(acc1[nt][0], 8 * s2);
                     *reinterpret_cast<bf16x8_t*>(lds + L::OFF_H1 + (0 * Q2 + 2 * (2 * w + nt) + s2) * 1024 + lane * 16) = hb;
 #pragma unroll
                     for (int r = 0; r < BODY1 / 4; ++r) { SGB_DSR(1); SGB_MFMA(1); SGB_VALU(8 / (BODY1 / 4)); SGB_MFMA(1); SGB_VALU(8 / (BODY1 / 4)); }
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
             // ---------------- layer 2 ----------------
 #pragma unroll
             for (int ct = 0; ct < CTN; ++ct) {
-                if (ct == 1 && has3) locate_lds(src, tile + 3 * stride, (it + 1) & 1);   // overwrites src[][] (rows(it+2) are issued)
+                if (ct == 1 && has3 && NCF_BF16_ABLATE != 5) locate_lds(src, tile + 3 * stride, (it + 1) & 1);   // overwrites src[][] (rows(it+2) are issued)
 #pragma unroll
                 for (int q = 0; q < Q2; ++q) {
                     if (q + AHEAD2 < Q2) hf[ct][(q + AHEAD2) % RING2] = *reinterpret_cast<const u32x4*>(hbase + (ct * Q2 + q + AHEAD2) * 1024);
@@ -694,11 +695,11 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
                         if (ct == 0) {
                             // phase C filler: one finished ct1 fragment of layer 1 per quarter of the body
                             const int nt = f >> 1, s2 = f & 1;
-                            const bf16x8_t hb = pack_relu8_int(acc1[nt][1], 8 * s2);
+                            const bf16x8_t hb = NCF_BF16_ABLATE == 5 ? as_bf16x8(hf[0][0]) : pack_relu8_int(acc1[nt][1], 8 * s2);
                             *reinterpret_cast<bf16x8_t*>(lds + L::OFF_H1 + (1 * Q2 + 2 * (2 * w + nt) + s2) * 1024 + lane * 16) = hb;
                         } else {
                             // phase D filler: a quarter of ct0's last-layer dot per quarter of the body
-                            part0 = dot_quarter(acc2[0], 32 * w, f, part0);
+                            if (NCF_BF16_ABLATE != 5) part0 = dot_quarter(acc2[0], 32 * w, f, part0);
                         }
 #pragma unroll
                         for (int r = 0; r < BODY2 / 4; ++r) { SGB_DSR(1); SGB_MFMA(1); SGB_VALU(16 / (BODY2 / 4)); }
@@ -748,6 +749,13 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
             WS_STAMP(5);
         }
         prev0 = part0;
+        if (NCF_BF16_ABLATE == 5) {                          // diagnostics: keep the MFMA results alive without reading them
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int ct = 0; ct < CTN; ++ct) asm volatile("" ::"a"(acc1[nt][ct]));
+            if constexpr (N2 > 0) asm volatile("" ::"a"(acc2[0]), "a"(acc2[1]));
+        }
         WS_STAMP(6);
     }
     if (oob_seen && a.oob) *a.oob = 1;
