@@ -163,7 +163,10 @@ class SparseDynamicProvider(DynamicContentProvider):
         cand_ids = np.asarray(cand)
         candidate_items = self.get_item_profile(cand_ids)
         targets_or_items2 = self.get_item_profile(np.asarray(third)) if for_ranking else torch.as_tensor(np.asarray(third), dtype=torch.float32)
-        ups = [self.user_pos[u] for u in users]
+        ups_all = np.asarray([self.user_pos[u] for u in users])
+        # one CSR row per DISTINCT user of the batch (the dense matrix of dynamic_profiles_provider.py:60-70 repeats a
+        # user's row for each of their samples); pair_row maps samples to rows
+        ups, pair_row = np.unique(ups_all, return_inverse=True)
         rated_ids = np.unique(np.concatenate([self.user_rated_items[p] for p in ups]))  # sorted (:59)
         cols, vals, counts = [], [], []
         for p in ups:
@@ -175,6 +178,7 @@ class SparseDynamicProvider(DynamicContentProvider):
         rowptr = torch.zeros(len(ups) + 1, dtype=torch.int64)
         rowptr[1:] = torch.cumsum(torch.as_tensor(counts), 0)
         ratings = SparseRatings(rowptr, torch.as_tensor(np.concatenate(cols), dtype=torch.int32),
-                                torch.as_tensor(np.concatenate(vals), dtype=torch.float32), len(rated_ids))
+                                torch.as_tensor(np.concatenate(vals), dtype=torch.float32), len(rated_ids),
+                                pair_row=torch.as_tensor(pair_row, dtype=torch.int64))
         user_matrix = ratings if self.sparse else ratings.to_dense(ratings.val)
         return cand_ids, rated_ids, candidate_items, self.get_item_profile(rated_ids), user_matrix, targets_or_items2

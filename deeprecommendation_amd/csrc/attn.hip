@@ -13,6 +13,7 @@
 // kernel is bound by gathered cache bandwidth, not by arithmetic.
 #include "ncf_common.h"
 #include <math.h>
+#include <type_traits>
 
 #ifndef ATT_UNROLL
 #define ATT_UNROLL 8   // measured (cfg 3, A/B): 2 -> 141.7 us, 4 -> 138.9, 8 -> 133.9, 16 -> 256 (registers)
@@ -29,6 +30,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     return v;
+}
+
+// Wave-wide reductions on the VALU (DPP row operations + 4 readlanes) instead of six dependent ds_bpermute round trips:
+// quad swaps, then half-row and row mirrors give every lane its 16-lane row's total; the four row totals are combined
+// from lanes 15 / 31 / 47 / 63.  The result is wave-uniform.  Used by the grouped kernel, whose single wave per SIMD
+// pair cannot hide LDS latency.  (Same pairing for max and sum: the sum's association order is fixed, run to run.)
+template <typename Op>
+__device__ __forceinline__ float wave_reduce_dpp(float v, Op op) {
+    auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));    // quad_perm [1,0,3,2]
+    v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));    // quad_perm [2,3,0,1]
+    v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror
+    v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 31));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 63));
+    return op(op(r0, r1), op(r2, r3));
 }
 
 // MODE 0: MLP (relu + w1 dot), 1: linear (A == 1, pc + pr), 2: cosine (dot of normalised rows)
@@ -206,6 +226,259 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ pc,
     (void)nnz;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K3, LDS-tiled form for batches in which several pairs share one rated set (evaluation batches grouped by user,
+// serving one user against the whole catalogue — reference webapp/backend.py:78-121).
+//
+// attn_kernel above gathers every pair's rated rows from L2 / the Infinity Cache: nnz·(A + Fdim)·4 bytes per PAIR
+// (197 KB at config 3).  Here the CSR has one row per USER, `grp_ptr`/`pair_ids` list each user's pairs, and a
+// 256-thread workgroup takes up to `ppw` pairs of one user: it stages the user's rated rows once, 64 entries at a
+// time, into LDS — the attention-projection rows pr[col_e, :] (row stride A+4 floats: a lane's 16-byte reads of ITS
+// entry's row are conflict-free) and the aggregation rows feat[col_e, :] — and every pair of the group is scored
+// against the staged tile.  Gathered bytes drop by the group size; the score loop runs out of LDS:
+//   lane = entry of the tile;  s_e = b1 + Σ_a w1[a]·relu(pc[b,a] + pr[e,a])   (pc row and w1 are LDS broadcasts)
+// Softmax is ONLINE over the tiles (running max m, running sum l, output rescaled by exp(m - m')), so a user with any
+// number of rated items needs no per-pair score storage:
+//   out[b,:] = bias + (Σ_e exp(s_e - m)·val_e·feat[col_e,:]) / l
+// which is the same weighted sum as attn_kernel's up to fp32 summation order (tests hold both to the oracle at 1e-5).
+// An empty or fully masked row gives l = 0 -> zeros + bias (the nan_to_num case, :208-209).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// FO = output registers per lane = ceil(Fdim / 64); NPF = 16-byte pieces of a tile each thread stages = (A + Fdim) / 32 rounded up to 4 / 8 / 16
+template <int MODE, int FO, int NPF>
+__global__ __launch_bounds__(512) void attn_grouped_kernel(const float* __restrict__ pc, int64_t ldpc, const float* __restrict__ pr,
+                                                           int64_t ldpr, int A, const float* __restrict__ w1, float b1,
+                                                           const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val, int64_t R, int64_t I,
+                                                           const int64_t* __restrict__ grp_ptr, const int64_t* __restrict__ pair_ids,
+                                                           const int64_t* __restrict__ wg_ptr, int ppw,
+                                                           const float* __restrict__ feat, int64_t ldfeat, int Fdim,
+                                                           const float* __restrict__ out_bias, float* __restrict__ out, int64_t ldout) {
+    constexpr int EC = 64;     // entries per tile = lanes
+    constexpr int MAXP = 4;    // pairs per wave (ppw <= 32)
+    constexpr int NT = 512, NW = NT / 64;   // 8 waves share a tile: 2 workgroups per CU give 4 waves per SIMD
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int AS = A + 4;
+    float* prc = reinterpret_cast<float*>(smem);           // [EC][AS]
+    float* fc = prc + EC * AS;                             // [EC][Fdim]
+    float* pcs = fc + EC * Fdim;                           // [ppw][A]
+    float* w1s = pcs + ppw * A;                            // [A]
+    float* vals = w1s + A;                                 // [EC]  val_e, 0 for a masked entry
+    int* oks = reinterpret_cast<int*>(vals + EC);          // [EC]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t g = blockIdx.x;
+    if (g >= wg_ptr[R]) return;                            // the grid is an upper bound (no host sync for its size)
+    int64_t lo = 0, hi = R;                                // row r with wg_ptr[r] <= g < wg_ptr[r+1]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (wg_ptr[mid] <= g) lo = mid; else hi = mid;
+    }
+    const int64_t r = lo;
+    const int64_t start = grp_ptr[r] + (g - wg_ptr[r]) * ppw;
+    const int64_t left = grp_ptr[r + 1] - start;
+    const int cnt = (int)(left < ppw ? left : ppw);
+    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    const int A4 = A / 4;
+    const bool fvec = (Fdim % 4 == 0) && (ldfeat % 4 == 0);
+    const int F4 = fvec ? Fdim / 4 : 0;
+    const int PIECES = EC * (A4 + F4);                     // float4 pieces of one tile (pr part, then feat part)
+
+    for (int idx = tid; idx < cnt * A4; idx += NT) {
+        const int j = idx / A4, c = idx % A4;
+        const int64_t b = pair_ids[start + j];
+        *reinterpret_cast<f32x4*>(pcs + j * A + 4 * c) = *reinterpret_cast<const f32x4*>(pc + b * ldpc + 4 * c);
+    }
+    if (MODE == 0)
+        for (int c = tid; c < A4; c += NT) *reinterpret_cast<f32x4*>(w1s + 4 * c) = *reinterpret_cast<const f32x4*>(w1 + 4 * c);
+
+    // A tile's rows travel global -> registers -> LDS; the loads of tile t+1 are issued before tile t is scored and
+    // land under its arithmetic (NPF pieces per thread in flight).
+    f32x4 stage[NPF];
+    float sval = 0.f;
+    int sok = 0;
+    auto fetch = [&](int64_t e0) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int idx = tid + NT * k;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < PIECES) {
+                const bool isf = idx >= EC * A4;
+                const int q = isf ? idx - EC * A4 : idx;
+                const int per = isf ? F4 : A4;
+                const int e = q / per, c = q % per;
+                const int64_t ee = e0 + e;
+                const int64_t i = ee < end ? (int64_t)col[ee] : -1;
+                if (i >= 0 && i < I) v = *reinterpret_cast<const f32x4*>((isf ? feat + i * ldfeat : pr + i * ldpr) + 4 * c);
+            }
+            stage[k] = v;
+        }
+        if (tid < EC) {
+            const int64_t e = e0 + tid;
+            const int64_t i = e < end ? (int64_t)col[e] : -1;
+            sok = i >= 0 && i < I;
+            sval = sok ? val[e] : 0.f;
+        }
+    };
+    auto commit = [&](int64_t e0) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int idx = tid + NT * k;
+            if (idx < PIECES) {
+                const bool isf = idx >= EC * A4;
+                const int q = isf ? idx - EC * A4 : idx;
+                const int per = isf ? F4 : A4;
+                const int e = q / per, c = q % per;
+                *reinterpret_cast<f32x4*>((isf ? fc + e * Fdim : prc + e * AS) + 4 * c) = stage[k];
+            }
+        }
+        if (tid < EC) {
+            oks[tid] = sok;
+            vals[tid] = sval;
+        }
+        if (!fvec) {   // feature rows that cannot be read as 16-byte pieces: staged directly (rare shapes)
+            for (int idx = tid; idx < EC * Fdim; idx += NT) {
+                const int e = idx / Fdim, f = idx % Fdim;
+                const int64_t ee = e0 + e;
+                const int64_t i = ee < end ? (int64_t)col[ee] : -1;
+                fc[e * Fdim + f] = (i >= 0 && i < I) ? feat[i * ldfeat + f] : 0.f;
+            }
+        }
+    };
+
+    float m[MAXP], l[MAXP], o[MAXP][FO];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        m[k] = -INFINITY;
+        l[k] = 0.f;
+#pragma unroll
+        for (int f = 0; f < FO; ++f) o[k][f] = 0.f;
+    }
+
+    if (beg < end) fetch(beg);
+    for (int64_t e0 = beg; e0 < end; e0 += EC) {
+        __syncthreads();                                   // the previous tile has been consumed (and pcs / w1s are written)
+        commit(e0);
+        __syncthreads();
+        if (e0 + EC < end) fetch(e0 + EC);                 // in flight while this tile is scored
+
+        const bool ok = oks[lane] != 0;
+        const float vl = vals[lane];
+        const float* myrow = prc + lane * AS;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int j = wave + NW * k;
+            if (j >= cnt) break;                           // wave-uniform
+            const float* pcj = pcs + j * A;
+            f32x2 s2 = {0.f, 0.f}, t2 = {0.f, 0.f};
+#pragma unroll 4
+            for (int c = 0; c < A4; ++c) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(myrow + 4 * c);
+                const f32x4 q = *reinterpret_cast<const f32x4*>(pcj + 4 * c);     // same address in every lane: broadcast
+                const f32x2 p01 = {p[0], p[1]}, p23 = {p[2], p[3]}, q01 = {q[0], q[1]}, q23 = {q[2], q[3]};
+                if (MODE == 0) {
+                    const f32x4 ww = *reinterpret_cast<const f32x4*>(w1s + 4 * c);
+                    const f32x2 w01 = {ww[0], ww[1]}, w23 = {ww[2], ww[3]};
+                    f32x2 u = q01 + p01, v = q23 + p23;    // v_pk_add_f32
+                    u = __builtin_elementwise_max(u, (f32x2){0.f, 0.f});
+                    v = __builtin_elementwise_max(v, (f32x2){0.f, 0.f});
+                    s2 = w01 * u + s2;                     // v_pk_fma_f32
+                    t2 = w23 * v + t2;
+                } else {
+                    s2 = q01 * p01 + s2;
+                    t2 = q23 * p23 + t2;
+                }
+            }
+            const float ssum = (s2[0] + t2[0]) + (s2[1] + t2[1]);
+            const float sc = ok ? ssum + (MODE == 0 ? b1 : 0.f) : -INFINITY;
+            const float mnew = fmaxf(m[k], wave_reduce_dpp(sc, [](float x, float y) { return fmaxf(x, y); }));
+            if (mnew == -INFINITY) continue;               // nothing valid so far (wave-uniform): m, l, o stay 0
+            const float scale = expf(m[k] - mnew);         // exp(-inf) = 0 on the first valid tile
+            const float pe = ok ? expf(sc - mnew) : 0.f;
+            l[k] = l[k] * scale + wave_reduce_dpp(pe, [](float x, float y) { return x + y; });
+            m[k] = mnew;
+            const float pv = pe * vl;                      // attended_user_matrix entry (:212)
+#pragma unroll
+            for (int f = 0; f < FO; ++f) o[k][f] *= scale;
+#pragma unroll
+            for (int e = 0; e < EC; ++e) {
+                const float a_e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), e));
+#pragma unroll
+                for (int f = 0; f < FO; ++f) {
+                    const int ff = f * 64 + lane;
+                    o[k][f] = fmaf(a_e, fc[e * Fdim + (ff < Fdim ? ff : 0)], o[k][f]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int j = wave + NW * k;
+        if (j >= cnt) break;
+        const int64_t b = pair_ids[start + j];
+        const float inv = l[k] > 0.f ? 1.0f / l[k] : 0.f;
+#pragma unroll
+        for (int f = 0; f < FO; ++f) {
+            const int ff = f * 64 + lane;
+            if (ff < Fdim) out[b * ldout + ff] = o[k][f] * inv + (out_bias ? out_bias[ff] : 0.f);
+        }
+    }
+}
+
+// ---- pairs listed row by row for the grouped kernel (a counting sort; order inside a row is irrelevant: every pair's
+// output is computed independently) ----
+__global__ void group_count_kernel(const int64_t* __restrict__ pair_row, int64_t B, int64_t R, int* __restrict__ counts,
+                                   int* __restrict__ bad) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int64_t r = pair_row[b];
+    if (r < 0 || r >= R) { *bad = 1; return; }
+    atomicAdd(&counts[r], 1);
+}
+// one workgroup: exclusive scans of counts -> grp_ptr and of ceil(counts / ppw) -> wg_ptr; cursor[r] = grp_ptr[r]
+__global__ __launch_bounds__(1024) void group_scan_kernel(const int* __restrict__ counts, int64_t R, int ppw,
+                                                          int64_t* __restrict__ grp_ptr, int64_t* __restrict__ wg_ptr,
+                                                          int* __restrict__ cursor) {
+    __shared__ int64_t sa[1024], sb[1024];
+    __shared__ int64_t carry_a, carry_b;
+    if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
+    __syncthreads();
+    for (int64_t base = 0; base < R; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t c = i < R ? counts[i] : 0;
+        const int64_t wgs = (c + ppw - 1) / ppw;
+        sa[threadIdx.x] = c;
+        sb[threadIdx.x] = wgs;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {         // Hillis-Steele inclusive scan
+            const int64_t va = threadIdx.x >= off ? sa[threadIdx.x - off] : 0;
+            const int64_t vb = threadIdx.x >= off ? sb[threadIdx.x - off] : 0;
+            __syncthreads();
+            sa[threadIdx.x] += va;
+            sb[threadIdx.x] += vb;
+            __syncthreads();
+        }
+        if (i < R) {
+            const int64_t ea = carry_a + sa[threadIdx.x] - c, eb = carry_b + sb[threadIdx.x] - wgs;
+            grp_ptr[i] = ea;
+            wg_ptr[i] = eb;
+            cursor[i] = (int)ea;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry_a += sa[1023]; carry_b += sb[1023]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { grp_ptr[R] = carry_a; wg_ptr[R] = carry_b; }
+}
+__global__ void group_scatter_kernel(const int64_t* __restrict__ pair_row, int64_t B, int64_t R, int* __restrict__ cursor,
+                                     int64_t* __restrict__ pair_ids) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int64_t r = pair_row[b];
+    if (r < 0 || r >= R) return;
+    pair_ids[atomicAdd(&cursor[r], 1)] = b;
+}
+
 // out[r,:] = x[r,:] / max(||x[r,:]||_2, 1e-12)   (torch.nn.functional.normalize(p=2, dim=1), attention_ncf.py:167-168)
 __global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t R, int E,
                                                                 float* __restrict__ out, int64_t ldo) {
@@ -263,4 +536,68 @@ extern "C" int ncf_attn_forward(int mode, const float* pc, int64_t ldpc, const f
     else LAUNCH(2);
 #undef LAUNCH
     return check_launch("ncf_attn_forward");
+}
+
+extern "C" int ncf_attn_forward_grouped(int mode, const float* pc, int64_t ldpc, const float* pr, int64_t ldpr, int A,
+                                        const float* w1, float b1, const int64_t* rowptr, const int32_t* col, const float* val,
+                                        int64_t R, int64_t I, const int64_t* grp_ptr, const int64_t* pair_ids,
+                                        const int64_t* wg_ptr, int64_t B, int pairs_per_wg, const float* feat, int64_t ldfeat,
+                                        int Fdim, const float* out_bias, float* out, int64_t ldout, ncf_stream_t stream) {
+    if (mode != NCF_ATT_MLP && mode != NCF_ATT_COS)
+        return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: mode %d has no LDS-tiled form (use ncf_attn_forward)", mode);
+    if (B < 0 || R < 0 || I < 0 || A <= 0 || Fdim <= 0) return fail(NCF_EINVAL, "ncf_attn_forward_grouped: bad sizes");
+    if (B == 0 || R == 0) return NCF_OK;
+    if (!pc || !pr || !rowptr || !grp_ptr || !pair_ids || !wg_ptr || !feat || !out)
+        return fail(NCF_EINVAL, "ncf_attn_forward_grouped: null pointer");
+    if (mode == NCF_ATT_MLP && !w1) return fail(NCF_EINVAL, "ncf_attn_forward_grouped: w1 is null");
+    if (ldpc < A || ldpr < A || ldfeat < Fdim || ldout < Fdim)
+        return fail(NCF_EINVAL, "ncf_attn_forward_grouped: leading dimension smaller than row");
+    if (pairs_per_wg < 1 || pairs_per_wg > 32) return fail(NCF_EINVAL, "ncf_attn_forward_grouped: pairs_per_wg must be 1..32");
+    if (A % 4 || ldpc % 4 || ldpr % 4 || A > 256 || Fdim > 256)
+        return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: needs A %% 4 == 0, A <= 256, Fdim <= 256 (A = %d, Fdim = %d)", A, Fdim);
+    if (!aligned16(pc) || !aligned16(pr) || (w1 && !aligned16(w1)) || (Fdim % 4 == 0 && ldfeat % 4 == 0 && !aligned16(feat)))
+        return fail(NCF_EINVAL, "ncf_attn_forward_grouped: operands must be 16-byte aligned");
+    const size_t lds = ((size_t)64 * (A + 4) + (size_t)64 * Fdim + (size_t)pairs_per_wg * A + A + 64 + 64) * 4;
+    if (lds > 160 * 1024) return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: tile needs %zu bytes of LDS", lds);
+    const bool fvec = Fdim % 4 == 0 && ldfeat % 4 == 0;
+    const int pieces_per_thread = (64 * (A / 4 + (fvec ? Fdim / 4 : 0)) + 511) / 512;   // <= 16 for A, Fdim <= 256
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((B + pairs_per_wg - 1) / pairs_per_wg + R);   // upper bound on sum_r ceil(n_r / ppw)
+#define LAUNCH1(M, F, P)                                                                                                          \
+    do {                                                                                                                       \
+        if (lds > 64 * 1024 &&                                                                                                 \
+            hipFuncSetAttribute((const void*)attn_grouped_kernel<M, F, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            (void)hipGetLastError();                                                                                           \
+            return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: cannot reserve %zu bytes of LDS", lds);                  \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((attn_grouped_kernel<M, F, P>), dim3(blocks), dim3(512), lds, s, pc, ldpc, pr, ldpr, A, w1, b1, rowptr, col, val, R, I, \
+                           grp_ptr, pair_ids, wg_ptr, pairs_per_wg, feat, ldfeat, Fdim, out_bias, out, ldout);                 \
+    } while (0)
+#define LAUNCH_P(M, F) do { if (pieces_per_thread <= 4) LAUNCH1(M, F, 4); else if (pieces_per_thread <= 8) LAUNCH1(M, F, 8); else LAUNCH1(M, F, 16); } while (0)
+#define LAUNCH_F(M) do { if (Fdim <= 64) LAUNCH_P(M, 1); else if (Fdim <= 128) LAUNCH_P(M, 2); else LAUNCH_P(M, 4); } while (0)
+    if (mode == NCF_ATT_MLP) LAUNCH_F(0);
+    else LAUNCH_F(2);
+#undef LAUNCH_F
+#undef LAUNCH_P
+#undef LAUNCH1
+    return check_launch("ncf_attn_forward_grouped");
+}
+
+extern "C" size_t ncf_group_pairs_workspace_bytes(int64_t n_rows) { return (size_t)(2 * (n_rows > 0 ? n_rows : 0) + 1) * sizeof(int); }
+
+extern "C" int ncf_group_pairs(const int64_t* pair_row, int64_t B, int64_t R, int pairs_per_wg, int64_t* grp_ptr, int64_t* pair_ids,
+                               int64_t* wg_ptr, void* workspace, size_t workspace_bytes, int32_t* oob, ncf_stream_t stream) {
+    if (B < 0 || R < 0 || pairs_per_wg < 1) return fail(NCF_EINVAL, "ncf_group_pairs: bad sizes");
+    if (!grp_ptr || !wg_ptr || (B > 0 && (!pair_row || !pair_ids)) || !workspace) return fail(NCF_EINVAL, "ncf_group_pairs: null pointer");
+    if (B >= (int64_t)1 << 31) return fail(NCF_EUNSUPPORTED, "ncf_group_pairs: more than 2^31 pairs");
+    if (workspace_bytes < ncf_group_pairs_workspace_bytes(R)) return fail(NCF_EWORKSPACE, "ncf_group_pairs: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    int* counts = (int*)workspace;
+    int* cursor = counts + R;
+    int* bad = oob ? oob : cursor + R;                     // the spare word of the workspace when the caller passes no flag
+    if (hipMemsetAsync(workspace, 0, ncf_group_pairs_workspace_bytes(R), s) != hipSuccess) return check_launch("ncf_group_pairs(memset)");
+    if (B > 0) hipLaunchKernelGGL(group_count_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, pair_row, B, R, counts, bad);
+    hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, s, counts, R, pairs_per_wg, grp_ptr, wg_ptr, cursor);
+    if (B > 0) hipLaunchKernelGGL(group_scatter_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, pair_row, B, R, cursor, pair_ids);
+    return check_launch("ncf_group_pairs");
 }

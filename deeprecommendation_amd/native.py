@@ -47,6 +47,11 @@ SIGNATURES = {
     "ncf_scale_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, ctypes.c_float, _c_p, _c_i64, _c_p]),
     "ncf_attn_forward": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
                                   _c_i64, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "ncf_attn_forward_grouped": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
+                                          _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_int, _c_p, _c_p,
+                                          _c_i64, _c_p]),
+    "ncf_group_pairs_workspace_bytes": (_c_size, [_c_i64]),
+    "ncf_group_pairs": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
     "ncf_edge_softmax_csr": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_score_folded_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "ncf_score_folded": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p,
@@ -425,6 +430,69 @@ def attn_forward(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[tor
     _check(lib.ncf_attn_forward(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), float(b1), _ptr(rowptr), _ptr(col), _ptr(val),
                                 B, I, _ptr(feat), ldf, Fdim, _ptr(out_bias), _ptr(out), out.stride(0), _ptr(wts), _stream(pc)))
     return out, wts[:col.numel()]
+
+
+def attn_grouped_supported(mode: int, A: int, Fdim: int) -> bool:
+    """Shapes the LDS-tiled grouped kernel takes (mirrors ncf_attn_forward_grouped's NCF_EUNSUPPORTED conditions)."""
+    return mode in (ATT_MLP, ATT_COS) and A % 4 == 0 and A <= 256 and Fdim <= 256
+
+
+def default_pairs_per_wg(B: int) -> int:
+    """Pairs of one rated set per 512-thread workgroup (4 per wave at 32).  Staging a tile costs the same whatever the
+    number of pairs scored against it, so fat workgroups win as soon as there are enough of them to occupy the chip:
+    measured at config 3 (4096 pairs, 64 users) 8 / 16 / 32 -> 82 / 76 / 59 us (tools/ab_attn_grouped.py)."""
+    return 32 if B >= 2048 else (16 if B >= 512 else 8)
+
+
+def group_pairs(pair_row: torch.Tensor, n_rows: int, pairs_per_wg: int):
+    """Pairs listed row by row for ncf_attn_forward_grouped: (grp_ptr (R+1), pair_ids (B), wg_ptr (R+1)), all int64 on
+    pair_row's device — a counting sort on the stream (ncf_group_pairs), no host synchronisation; an out-of-range row
+    raises at the next check_oob()."""
+    lib = load_library()
+    _dev(pair_row, "pair_row")
+    if pair_row.dtype != torch.int64 or pair_row.dim() != 1 or not pair_row.is_contiguous():
+        raise ValueError("pair_row must be contiguous 1-D int64")
+    B, R, dev = pair_row.numel(), int(n_rows), pair_row.device
+    grp_ptr = torch.empty(R + 1, dtype=torch.int64, device=dev)
+    wg_ptr = torch.empty(R + 1, dtype=torch.int64, device=dev)
+    pair_ids = torch.empty(max(B, 1), dtype=torch.int64, device=dev)
+    nbytes = lib.ncf_group_pairs_workspace_bytes(R)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _check(lib.ncf_group_pairs(_ptr(pair_row), B, R, int(pairs_per_wg), _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr), _ptr(ws), nbytes,
+                               _ptr(_oob_flag(dev)), _stream(pair_row)))
+    return grp_ptr, pair_ids[:B], wg_ptr
+
+
+def attn_forward_grouped(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[torch.Tensor], b1: float,
+                         rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, pair_row: torch.Tensor,
+                         feat: torch.Tensor, out_bias: Optional[torch.Tensor] = None, pairs_per_wg: Optional[int] = None,
+                         grouping=None):
+    """LDS-tiled attention for pairs that share rated sets: CSR row ``pair_row[b]`` is pair b's set.  Returns out_feat
+    (B, Fdim); attention weights are not produced (attn_forward on the expanded CSR does that).  ``grouping`` =
+    (group_pairs(pair_row, R, ppw), ppw) computed earlier for this batch skips the sort."""
+    lib = load_library()
+    _dev(pc, "pc")
+    B, A, ldpc = _rows2d(pc, "pc")
+    I, A2, ldpr = _rows2d(pr, "pr")
+    I2, Fdim, ldf = _rows2d(feat, "feat")
+    if A != A2 or I != I2:
+        raise ValueError("attention operand shapes disagree")
+    if rowptr.dtype != torch.int64 or col.dtype != torch.int32 or val.dtype != torch.float32:
+        raise TypeError("CSR must be (int64 rowptr, int32 col, fp32 val)")
+    if pair_row.numel() != B:
+        raise ValueError("pair_row must name one CSR row per pair")
+    R = rowptr.numel() - 1
+    if grouping is not None:
+        (grp_ptr, pair_ids, wg_ptr), pairs_per_wg = grouping
+    else:
+        if pairs_per_wg is None:
+            pairs_per_wg = default_pairs_per_wg(B)
+        grp_ptr, pair_ids, wg_ptr = group_pairs(pair_row.to(torch.int64).contiguous(), R, pairs_per_wg)
+    out = torch.empty((B, Fdim), dtype=torch.float32, device=pc.device)
+    _check(lib.ncf_attn_forward_grouped(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), float(b1), _ptr(rowptr), _ptr(col),
+                                        _ptr(val), R, I, _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr), B, int(pairs_per_wg),
+                                        _ptr(feat), ldf, Fdim, _ptr(out_bias), _ptr(out), out.stride(0), _stream(pc)))
+    return out
 
 
 def l2_normalize_rows(x: torch.Tensor) -> torch.Tensor:

@@ -6,7 +6,8 @@ from ..models.attention_ncf import SparseRatings
 
 def _dev(x, device):
     if isinstance(x, SparseRatings):
-        return SparseRatings(x.rowptr.to(device), x.col.to(device), x.val.to(device), x.num_items)
+        return SparseRatings(x.rowptr.to(device), x.col.to(device), x.val.to(device), x.num_items,
+                             None if x.pair_row is None else x.pair_row.to(device))
     return x.float().to(device)
 
 

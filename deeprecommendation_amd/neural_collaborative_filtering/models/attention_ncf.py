@@ -28,10 +28,36 @@ from .basic_ncf import _ScoringMixin
 class SparseRatings:
     """CSR form of the (B, I) ``user_matrix``: row b owns entries [rowptr[b], rowptr[b+1]) with ``col`` = position in
     the rated-item list and ``val`` = the non-zero normalised rating.  Providers can emit this directly instead of
-    the dense matrix (which is 2·B·I floats of mostly zeros)."""
+    the dense matrix (which is 2·B·I floats of mostly zeros).
 
-    def __init__(self, rowptr, col, val, num_items):
+    ``pair_row`` (optional, (B,) int64): the CSR then has one row per DISTINCT user of the batch and pair b uses row
+    ``pair_row[b]`` — the dense matrix repeats a user's row for each of their pairs (dynamic_datasets.py:24-40); sharing
+    it is what lets the LDS-tiled attention kernel stage a user's rated rows once for all of their pairs."""
+
+    GROUPED_MIN_PAIRS_PER_ROW = 4   # below this the per-pair kernel is used (nothing to share)
+
+    def __init__(self, rowptr, col, val, num_items, pair_row=None):
         self.rowptr, self.col, self.val, self.num_items = rowptr, col, val, int(num_items)
+        self.pair_row = pair_row
+
+    @property
+    def num_pairs(self) -> int:
+        return int(self.pair_row.numel()) if self.pair_row is not None else int(self.rowptr.numel() - 1)
+
+    def expanded(self) -> "SparseRatings":
+        """Per-pair CSR (row b = pair b) of a shared-row instance; self if rows are not shared."""
+        if self.pair_row is None:
+            return self
+        pr = self.pair_row.to(torch.int64)
+        counts = (self.rowptr[1:] - self.rowptr[:-1])[pr]
+        rowptr = torch.zeros(pr.numel() + 1, dtype=torch.int64, device=self.rowptr.device)
+        rowptr[1:] = torch.cumsum(counts, 0)
+        # entry k of pair b is entry rowptr_shared[pair_row[b]] + k of the shared arrays
+        owner = torch.repeat_interleave(torch.arange(pr.numel(), device=pr.device), counts)
+        src = self.rowptr[:-1][pr][owner] + (torch.arange(owner.numel(), device=pr.device) - rowptr[:-1][owner])
+        ex = SparseRatings(rowptr, self.col[src].contiguous(), self.val[src].contiguous(), self.num_items)
+        ex.shared_entry = src   # entry of the shared arrays each expanded entry came from
+        return ex
 
     @staticmethod
     def from_dense(user_matrix: torch.Tensor) -> "SparseRatings":
@@ -43,6 +69,9 @@ class SparseRatings:
                              user_matrix.shape[1])
 
     def to_dense(self, values: torch.Tensor) -> torch.Tensor:
+        if self.pair_row is not None:
+            ex = self.expanded()   # `values` may be aligned with the shared entries (e.g. self.val) or the expanded ones
+            return ex.to_dense(values[ex.shared_entry] if values.numel() == self.col.numel() else values)
         B = self.rowptr.numel() - 1
         rows = torch.repeat_interleave(torch.arange(B, device=values.device), self.rowptr[1:] - self.rowptr[:-1])
         out = torch.zeros((B, self.num_items), dtype=values.dtype, device=values.device)
@@ -136,6 +165,15 @@ class AttentionNCF(_ScoringMixin, NCF):
                 mode = native.ATT_MLP
             else:
                 mode, w1, b1 = native.ATT_LINEAR, None, 0.0
+        shared = ratings.pair_row is not None
+        if (shared and not return_attention_weights and native.attn_grouped_supported(mode, pc.shape[1], proj.shape[1])
+                and ratings.num_pairs >= SparseRatings.GROUPED_MIN_PAIRS_PER_ROW * (ratings.rowptr.numel() - 1)):
+            # several pairs per rated set: stage each set once per workgroup in LDS (K3 grouped form)
+            user_emb = native.attn_forward_grouped(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val,
+                                                   ratings.pair_row, proj, out_bias=lu.bias.detach())
+            return self._score(cand_emb, None, user_emb, None)
+        if shared:
+            ratings = ratings.expanded()
         user_emb, wts = native.attn_forward(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val, proj,
                                             out_bias=lu.bias.detach())
         out = self._score(cand_emb, None, user_emb, None)  # cat(candidate_emb, user_emb): :219
@@ -146,6 +184,7 @@ class AttentionNCF(_ScoringMixin, NCF):
     # ------------------------------------------------------------------------------------------ torch training path
     def _forward_train(self, candidate_items, rated_items, user_matrix, return_attention_weights):
         if isinstance(user_matrix, SparseRatings):
+            user_matrix = user_matrix.expanded()
             user_matrix = user_matrix.to_dense(user_matrix.val)
         B, I = candidate_items.shape[0], rated_items.shape[0]
         cand_emb = self.ItemEmbeddings(candidate_items)

@@ -216,6 +216,35 @@ int ncf_attn_forward(int mode,
                      float* dev_weights,
                      ncf_stream_t stream);
 
+/* The same computation for batches in which several pairs share one rated set (evaluation batches grouped by user;
+ * serving one user against the whole catalogue, reference webapp/backend.py:78-121), LDS-tiled: the CSR has one row
+ * per USER (n_rows rows), the B pairs are listed user by user —
+ *   dev_grp_ptr (n_rows+1):  pairs of row r are dev_pair_ids[grp_ptr[r] .. grp_ptr[r+1])  (indices into pc / out rows)
+ *   dev_wg_ptr  (n_rows+1):  exclusive prefix sum of ceil(pairs_of_row / pairs_per_wg)     (workgroups per row)
+ * — and a workgroup stages a user's rated rows once per 64 entries into LDS for up to pairs_per_wg (1..32) pairs, with
+ * an online softmax over the tiles.  Same result as ncf_attn_forward on the expanded per-pair CSR up to fp32 summation
+ * order; attention weights are not returned (use ncf_attn_forward for models/attention_ncf.py:224).
+ * NCF_EUNSUPPORTED (fall back to ncf_attn_forward): mode NCF_ATT_LINEAR, A % 4 != 0, A > 256, Fdim > 256. */
+int ncf_attn_forward_grouped(int mode,
+                             const float* dev_pc, int64_t ldpc, const float* dev_pr, int64_t ldpr, int A,
+                             const float* dev_w1, float b1,
+                             const int64_t* dev_rowptr, const int32_t* dev_col, const float* dev_val,
+                             int64_t n_rows, int64_t n_rated,
+                             const int64_t* dev_grp_ptr, const int64_t* dev_pair_ids, const int64_t* dev_wg_ptr,
+                             int64_t B, int pairs_per_wg,
+                             const float* dev_feat, int64_t ldfeat, int Fdim, const float* dev_out_bias,
+                             float* dev_out_feat, int64_t ldout, ncf_stream_t stream);
+
+/* Builds dev_grp_ptr / dev_pair_ids / dev_wg_ptr of ncf_attn_forward_grouped from dev_pair_row (B,) = the CSR row of
+ * each pair (what the dense user_matrix expresses by repeating a user's row, dynamic_datasets.py:24-40): a counting
+ * sort on the stream, no host synchronisation.  The order of a row's pairs inside dev_pair_ids is unspecified (each
+ * pair's output is independent of it).  A pair_row outside [0, n_rows) sets *dev_oob_flag (sticky) and drops the pair.
+ * workspace: ncf_group_pairs_workspace_bytes(n_rows) bytes of device memory. */
+size_t ncf_group_pairs_workspace_bytes(int64_t n_rows);
+int ncf_group_pairs(const int64_t* dev_pair_row, int64_t B, int64_t n_rows, int pairs_per_wg,
+                    int64_t* dev_grp_ptr, int64_t* dev_pair_ids, int64_t* dev_wg_ptr,
+                    void* dev_workspace, size_t workspace_bytes, int32_t* dev_oob_flag, ncf_stream_t stream);
+
 /* out[r, :] = x[r, :] / max(||x[r, :]||_2, 1e-12) — torch.nn.functional.normalize(p=2, dim=1) of the cosine
  * variant, models/attention_ncf.py:167-168. */
 int ncf_l2_normalize_rows(const float* dev_x, int64_t ldx, int64_t R, int E, float* dev_out, int64_t ldout,

@@ -11,6 +11,13 @@ from test_gpu_basic import assert_close
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def native(gpu):
+    from deeprecommendation_amd import native as n
+    n.load_library()
+    return n
+
+
 def _model(kw, state, gpu):
     from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
     m = AttentionNCF(**kw)
@@ -149,3 +156,100 @@ def test_serving_shape_one_user_whole_catalogue(gpu):
     top_ref = torch.topk(ref_out.view(-1), k).indices
     top = torch.topk(out.view(-1).cpu(), k).indices
     assert torch.equal(top, top_ref)
+
+
+# ----------------------------------------------------------------------------- grouped (LDS-tiled) form
+def _shared_rows(R, I, nnz_max, B, gpu, seed, empty_row=True, bad_cols=False):
+    """R rated sets (ragged, one possibly empty) shared by B pairs in random order."""
+    g = torch.Generator().manual_seed(seed)
+    counts = torch.randint(1, nnz_max + 1, (R,), generator=g)
+    if empty_row:
+        counts[R // 2] = 0
+    rowptr = torch.zeros(R + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    col = torch.cat([torch.randperm(I, generator=g)[:int(c)].sort().values for c in counts]).to(torch.int32)
+    if bad_cols:
+        col[::7] = I + 3      # out-of-range positions are masked entries (-inf score), never a fault
+        col[3::11] = -1
+    val = torch.randint(1, 11, (int(rowptr[-1]),), generator=g).float() * 0.5 - 2.9
+    pair_row = torch.randint(0, R, (B,), generator=g)
+    return rowptr.to(gpu), col.to(gpu), val.to(gpu), pair_row.to(gpu)
+
+
+@pytest.mark.parametrize("mode", ["mlp", "cos"])
+@pytest.mark.parametrize("A,Fdim,R,nnz_max,B,ppw", [
+    (128, 64, 9, 300, 500, None),      # cfg-3 shaped: several 64-entry tiles per user, ragged last tile
+    (64, 128, 3, 40, 37, 4),           # fewer entries than one tile; two output registers per lane
+    (8, 20, 5, 130, 64, 16),           # Fdim not a multiple of 4 (scalar staging), 16 pairs per workgroup
+    (256, 256, 2, 70, 9, 1),           # the largest tile the entry accepts (> 64 KB of LDS), one pair per workgroup
+])
+def test_attention_grouped_equals_per_pair_kernel(native, gpu, mode, A, Fdim, R, nnz_max, B, ppw):
+    """ncf_attn_forward_grouped on shared rows == ncf_attn_forward on the expanded per-pair CSR (both within 1e-5 of a
+    float64 evaluation), incl. an empty rated set, masked (out-of-range) positions and pairs in random user order."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import SparseRatings
+    I = 400
+    g = torch.Generator(device=gpu).manual_seed(A + Fdim)
+    pr = torch.randn(I, A, device=gpu, generator=g) * 0.4
+    pc = torch.randn(B, A, device=gpu, generator=g) * 0.4
+    feat = torch.randn(I, Fdim, device=gpu, generator=g)
+    bias = torch.randn(Fdim, device=gpu, generator=g)
+    w1 = torch.randn(A, device=gpu, generator=g) * 0.3
+    m = native.ATT_MLP if mode == "mlp" else native.ATT_COS
+    rowptr, col, val, pair_row = _shared_rows(R, I, nnz_max, B, gpu, seed=R * 100 + B, bad_cols=(A == 128))
+    out_g = native.attn_forward_grouped(m, pc, pr, w1 if mode == "mlp" else None, 0.25, rowptr, col, val, pair_row, feat,
+                                        out_bias=bias, pairs_per_wg=ppw)
+    ex = SparseRatings(rowptr, col, val, I, pair_row=pair_row).expanded()
+    out_p, _ = native.attn_forward(m, pc, pr, w1 if mode == "mlp" else None, 0.25, ex.rowptr, ex.col, ex.val, feat, out_bias=bias)
+    # float64 restatement on the CPU
+    pcd, prd, fd, w1d = pc.cpu().double(), pr.cpu().double(), feat.cpu().double(), w1.cpu().double()
+    ref = torch.zeros(B, Fdim, dtype=torch.float64)
+    rp, cc, vv, prow = rowptr.cpu(), col.cpu().long(), val.cpu().double(), pair_row.cpu()
+    for b in range(B):
+        r = int(prow[b])
+        c, v = cc[rp[r]:rp[r + 1]], vv[rp[r]:rp[r + 1]]
+        ok = (c >= 0) & (c < I)
+        c, v = c[ok], v[ok]
+        if c.numel():
+            if mode == "mlp":
+                s = (torch.relu(pcd[b][None, :] + prd[c]) * w1d).sum(1) + 0.25
+            else:
+                s = (pcd[b][None, :] * prd[c]).sum(1)
+            w = torch.softmax(s, 0)
+            ref[b] = ((w * v)[:, None] * fd[c]).sum(0)
+    ref += bias.cpu().double()
+    assert_close(out_p, ref.float())
+    assert_close(out_g, ref.float())
+    empty = (rp[1:] - rp[:-1])[prow] == 0
+    if bool(empty.any()):
+        assert torch.equal(out_g.cpu()[empty], bias.cpu().expand(int(empty.sum()), Fdim))   # zeros + bias, not NaN
+
+
+def test_attention_model_takes_the_grouped_path_for_shared_rows(gpu, monkeypatch):
+    """AttentionNCF.forward with a shared-row SparseRatings (what SparseDynamicProvider collates) runs the LDS-tiled
+    kernel when users repeat, and agrees with the dense-matrix call and the oracle; with return_attention_weights it
+    falls back to the per-pair kernel and still returns the (B, I) weights."""
+    from deeprecommendation_amd import native
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import SparseRatings
+    m, cand, rated, um_rows = _random_case(B=6, I=150, Fdim=40, IE=64, UE=64, A=128, hidden=[256, 128], density=0.4, seed=11)
+    g = torch.Generator().manual_seed(2)
+    B = 96
+    pair_row = torch.randint(0, 6, (B,), generator=g)
+    cand = torch.rand(B, 40, generator=g)
+    um = um_rows[pair_row]                                  # the dense matrix repeats a user's row per pair
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    ref_out, ref_att = O.attention_ncf_forward(state, cand, rated, um, return_attention_weights=True)
+    m.to(gpu)
+    shared_rows = SparseRatings.from_dense(um_rows.to(gpu))
+    shared = SparseRatings(shared_rows.rowptr, shared_rows.col, shared_rows.val, shared_rows.num_items, pair_row=pair_row.to(gpu))
+    calls = []
+    real = native.attn_forward_grouped
+    monkeypatch.setattr(native, "attn_forward_grouped", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        out_shared = m(cand.to(gpu), rated.to(gpu), shared)
+        out_dense = m(cand.to(gpu), rated.to(gpu), um.to(gpu))
+        out_w, att = m(cand.to(gpu), rated.to(gpu), shared, return_attention_weights=True)
+    assert calls == [1]
+    assert_close(out_shared, ref_out)
+    assert_close(out_dense, ref_out)
+    assert_close(out_w, ref_out)
+    assert_close(att, ref_att)
