@@ -365,31 +365,50 @@ __global__ __launch_bounds__(512) void attn_grouped_kernel(const float* __restri
         const bool ok = oks[lane] != 0;
         const float vl = vals[lane];
         const float* myrow = prc + lane * AS;
+        // The wave's pairs (np of them, j = wave + NW*k) are scored TOGETHER: one read of the entry's row piece and of
+        // w1 serves all of them, and their dependency chains interleave (2 waves per SIMD cannot hide LDS latency on
+        // a single chain).  1, 2 or 4 slots are computed; slots k >= np work on pair 0's row and are ignored.
+        const int np = cnt > wave ? (cnt - wave + NW - 1) / NW : 0;   // wave-uniform
+        auto score_tile = [&](auto slots) {
+        constexpr int NS = decltype(slots)::value;             // slots computed: 1, 2 or 4 (>= np)
+        const float* pcj[NS];
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k) {
-            const int j = wave + NW * k;
-            if (j >= cnt) break;                           // wave-uniform
-            const float* pcj = pcs + j * A;
-            f32x2 s2 = {0.f, 0.f}, t2 = {0.f, 0.f};
-#pragma unroll 4
-            for (int c = 0; c < A4; ++c) {
-                const f32x4 p = *reinterpret_cast<const f32x4*>(myrow + 4 * c);
-                const f32x4 q = *reinterpret_cast<const f32x4*>(pcj + 4 * c);     // same address in every lane: broadcast
-                const f32x2 p01 = {p[0], p[1]}, p23 = {p[2], p[3]}, q01 = {q[0], q[1]}, q23 = {q[2], q[3]};
+        for (int k = 0; k < NS; ++k) pcj[k] = pcs + (k < np ? wave + NW * k : wave) * A;
+        f32x2 s2[NS], t2[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { s2[k] = f32x2{0.f, 0.f}; t2[k] = f32x2{0.f, 0.f}; }
+#pragma unroll 2
+        for (int c = 0; c < A4; ++c) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(myrow + 4 * c);
+            const f32x2 p01 = {p[0], p[1]}, p23 = {p[2], p[3]};
+            f32x2 w01 = {0.f, 0.f}, w23 = {0.f, 0.f};
+            if (MODE == 0) {
+                const f32x4 ww = *reinterpret_cast<const f32x4*>(w1s + 4 * c);   // same address in every lane: broadcast
+                w01 = f32x2{ww[0], ww[1]};
+                w23 = f32x2{ww[2], ww[3]};
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(pcj[k] + 4 * c);  // broadcast
+                const f32x2 q01 = {q[0], q[1]}, q23 = {q[2], q[3]};
                 if (MODE == 0) {
-                    const f32x4 ww = *reinterpret_cast<const f32x4*>(w1s + 4 * c);
-                    const f32x2 w01 = {ww[0], ww[1]}, w23 = {ww[2], ww[3]};
                     f32x2 u = q01 + p01, v = q23 + p23;    // v_pk_add_f32
                     u = __builtin_elementwise_max(u, (f32x2){0.f, 0.f});
                     v = __builtin_elementwise_max(v, (f32x2){0.f, 0.f});
-                    s2 = w01 * u + s2;                     // v_pk_fma_f32
-                    t2 = w23 * v + t2;
+                    s2[k] = w01 * u + s2[k];               // v_pk_fma_f32
+                    t2[k] = w23 * v + t2[k];
                 } else {
-                    s2 = q01 * p01 + s2;
-                    t2 = q23 * p23 + t2;
+                    s2[k] = q01 * p01 + s2[k];
+                    t2[k] = q23 * p23 + t2[k];
                 }
             }
-            const float ssum = (s2[0] + t2[0]) + (s2[1] + t2[1]);
+        }
+        float pv[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            pv[k] = 0.f;
+            if (k >= np) continue;                         // wave-uniform
+            const float ssum = (s2[k][0] + t2[k][0]) + (s2[k][1] + t2[k][1]);
             const float sc = ok ? ssum + (MODE == 0 ? b1 : 0.f) : -INFINITY;
             const float mnew = fmaxf(m[k], wave_reduce_dpp(sc, [](float x, float y) { return fmaxf(x, y); }));
             if (mnew == -INFINITY) continue;               // nothing valid so far (wave-uniform): m, l, o stay 0
@@ -397,19 +416,29 @@ __global__ __launch_bounds__(512) void attn_grouped_kernel(const float* __restri
             const float pe = ok ? expf(sc - mnew) : 0.f;
             l[k] = l[k] * scale + wave_reduce_dpp(pe, [](float x, float y) { return x + y; });
             m[k] = mnew;
-            const float pv = pe * vl;                      // attended_user_matrix entry (:212)
+            pv[k] = pe * vl;                               // attended_user_matrix entry (:212)
 #pragma unroll
             for (int f = 0; f < FO; ++f) o[k][f] *= scale;
+        }
+#pragma unroll 16
+        for (int e = 0; e < EC; ++e) {
+            float fv[FO];
 #pragma unroll
-            for (int e = 0; e < EC; ++e) {
-                const float a_e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), e));
+            for (int f = 0; f < FO; ++f) {
+                const int ff = f * 64 + lane;
+                fv[f] = fc[e * Fdim + (ff < Fdim ? ff : 0)];
+            }
 #pragma unroll
-                for (int f = 0; f < FO; ++f) {
-                    const int ff = f * 64 + lane;
-                    o[k][f] = fmaf(a_e, fc[e * Fdim + (ff < Fdim ? ff : 0)], o[k][f]);
-                }
+            for (int k = 0; k < NS; ++k) {
+                const float a_e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv[k]), e));
+#pragma unroll
+                for (int f = 0; f < FO; ++f) o[k][f] = fmaf(a_e, fv[f], o[k][f]);
             }
         }
+            };
+        if (np > 2) score_tile(std::integral_constant<int, 4>{});
+        else if (np == 2) score_tile(std::integral_constant<int, 2>{});
+        else if (np == 1) score_tile(std::integral_constant<int, 1>{});
     }
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
