@@ -499,6 +499,61 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int* __restrict_
     }
     if (threadIdx.x == 0) { grp_ptr[R] = carry_a; wg_ptr[R] = carry_b; }
 }
+// the three steps in ONE 1024-thread workgroup for small batches (an evaluation batch is a few thousand pairs: three
+// launches and a memset cost more than the work).  Counters and cursors live in LDS when the rows fit (LDS atomics: a
+// batch of 4096 pairs over 64 users puts 64 increments on each counter — 20 us with global atomics, 4 with LDS ones).
+template <bool LDS_COUNTERS>
+__global__ __launch_bounds__(1024) void group_small_kernel(const int64_t* __restrict__ pair_row, int64_t B, int64_t R, int ppw,
+                                                           int* __restrict__ gcounts, int* __restrict__ gcursor, int* __restrict__ bad,
+                                                           int64_t* __restrict__ grp_ptr, int64_t* __restrict__ wg_ptr,
+                                                           int64_t* __restrict__ pair_ids) {
+    constexpr int LDS_ROWS = 4096;
+    __shared__ int lcounts[LDS_COUNTERS ? LDS_ROWS : 1], lcursor[LDS_COUNTERS ? LDS_ROWS : 1];
+    __shared__ int sa[1024], sb[1024];
+    __shared__ int carry_a, carry_b;
+    int* counts = LDS_COUNTERS ? lcounts : gcounts;
+    int* cursor = LDS_COUNTERS ? lcursor : gcursor;
+    for (int64_t i = threadIdx.x; i < R; i += 1024) counts[i] = 0;
+    if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
+    __syncthreads();
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const int64_t r = pair_row[b];
+        if (r < 0 || r >= R) *bad = 1;
+        else atomicAdd(&counts[r], 1);
+    }
+    __syncthreads();
+    for (int64_t base = 0; base < R; base += 1024) {       // B <= 32768: the sums fit 32 bits
+        const int64_t i = base + threadIdx.x;
+        const int c = i < R ? counts[i] : 0;
+        const int wgs = (c + ppw - 1) / ppw;
+        sa[threadIdx.x] = c;
+        sb[threadIdx.x] = wgs;
+        __syncthreads();
+        const int n = (int)(R - base < 1024 ? R - base : 1024);
+        for (int off = 1; off < n; off <<= 1) {            // Hillis-Steele inclusive scan over the rows present
+            const int va = threadIdx.x >= off ? sa[threadIdx.x - off] : 0;
+            const int vb = threadIdx.x >= off ? sb[threadIdx.x - off] : 0;
+            __syncthreads();
+            sa[threadIdx.x] += va;
+            sb[threadIdx.x] += vb;
+            __syncthreads();
+        }
+        if (i < R) {
+            const int ea = carry_a + sa[threadIdx.x] - c, eb = carry_b + sb[threadIdx.x] - wgs;
+            grp_ptr[i] = ea;
+            wg_ptr[i] = eb;
+            cursor[i] = ea;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry_a += sa[n - 1]; carry_b += sb[n - 1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { grp_ptr[R] = carry_a; wg_ptr[R] = carry_b; }
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const int64_t r = pair_row[b];
+        if (r >= 0 && r < R) pair_ids[atomicAdd(&cursor[r], 1)] = b;
+    }
+}
 __global__ void group_scatter_kernel(const int64_t* __restrict__ pair_row, int64_t B, int64_t R, int* __restrict__ cursor,
                                      int64_t* __restrict__ pair_ids) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -624,6 +679,11 @@ extern "C" int ncf_group_pairs(const int64_t* pair_row, int64_t B, int64_t R, in
     int* counts = (int*)workspace;
     int* cursor = counts + R;
     int* bad = oob ? oob : cursor + R;                     // the spare word of the workspace when the caller passes no flag
+    if (B <= 32768 && R <= 32768) {
+        if (R <= 4096) hipLaunchKernelGGL(group_small_kernel<true>, dim3(1), dim3(1024), 0, s, pair_row, B, R, pairs_per_wg, counts, cursor, bad, grp_ptr, wg_ptr, pair_ids);
+        else hipLaunchKernelGGL(group_small_kernel<false>, dim3(1), dim3(1024), 0, s, pair_row, B, R, pairs_per_wg, counts, cursor, bad, grp_ptr, wg_ptr, pair_ids);
+        return check_launch("ncf_group_pairs");
+    }
     if (hipMemsetAsync(workspace, 0, ncf_group_pairs_workspace_bytes(R), s) != hipSuccess) return check_launch("ncf_group_pairs(memset)");
     if (B > 0) hipLaunchKernelGGL(group_count_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, pair_row, B, R, counts, bad);
     hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, s, counts, R, pairs_per_wg, grp_ptr, wg_ptr, cursor);

@@ -155,6 +155,10 @@ __global__ __launch_bounds__(256) void linear_rs_kernel(const float* __restrict_
     const int i = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * (4 / KS) + wave / KS;
     const int ks = wave % KS;
+    // gridDim.y column blocks of 32*NT outputs each (skinny problems run narrower blocks to fill the chip)
+    W += (int64_t)blockIdx.y * 32 * NT * ldw;
+    C += (int64_t)blockIdx.y * 32 * NT;
+    if (bias) bias += blockIdx.y * 32 * NT;
     const bool tile_ok = tile * 32 < M;  // wave-uniform
     const int64_t m = tile * 32 + i;
     const float* arow = A + (m < M ? m : (M - 1)) * lda + 4 * h;
@@ -229,11 +233,11 @@ __global__ __launch_bounds__(256) void linear_rs_kernel(const float* __restrict_
 
 template <int NT, int KS>
 static void launch_rs(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
-                      int64_t M, int K, bool relu, hipStream_t s) {
+                      int64_t M, int K, bool relu, hipStream_t s, int col_blocks = 1) {
     const int64_t tiles = (M + 31) / 32;
-    const unsigned blocks = (unsigned)((tiles + (4 / KS) - 1) / (4 / KS));
-    if (relu) hipLaunchKernelGGL((linear_rs_kernel<NT, KS, true>), dim3(blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
-    else hipLaunchKernelGGL((linear_rs_kernel<NT, KS, false>), dim3(blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
+    const dim3 grid((unsigned)((tiles + (4 / KS) - 1) / (4 / KS)), (unsigned)col_blocks);
+    if (relu) hipLaunchKernelGGL((linear_rs_kernel<NT, KS, true>), grid, dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
+    else hipLaunchKernelGGL((linear_rs_kernel<NT, KS, false>), grid, dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
 }
 
 template <int NT>
@@ -241,6 +245,10 @@ static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ld
                          int64_t M, int K, bool relu, hipStream_t s) {
     const int64_t tiles = (M + 31) / 32;
     if constexpr (NT <= 4) {
+        // Skinny and deep (the 4096 x 2094 -> 64 candidate Linear of AttentionNCF: 128 row tiles): one 32-column block
+        // per workgroup so that tiles * NT workgroups share the chip — the rows of A are re-read once per column block
+        // (from L2), each wave's MFMA chain is NT times shorter; same split-K order, bit-identical results.
+        if (NT > 1 && tiles * NT <= 512 && K >= 512) return launch_rs<1, 4>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s, NT);
         if (tiles <= 1024 && K >= 64) return launch_rs<NT, 4>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
         if (tiles <= 2048 && K >= 32) return launch_rs<NT, 2>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
     }

@@ -253,3 +253,32 @@ def test_attention_model_takes_the_grouped_path_for_shared_rows(gpu, monkeypatch
     assert_close(out_dense, ref_out)
     assert_close(out_w, ref_out)
     assert_close(att, ref_att)
+
+
+def test_attention_grouped_large_batch_matches_per_pair(native, gpu):
+    """40 000 pairs over 50 users: the multi-launch grouping path (ncf_group_pairs above 32 768 pairs) and 32 pairs per
+    workgroup; the grouped kernel must agree with the per-pair kernel on the expanded CSR, and the grouping must be a
+    permutation of the pairs, row by row."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import SparseRatings
+    I, A, Fdim, R, B = 500, 64, 64, 50, 40000
+    g = torch.Generator(device=gpu).manual_seed(3)
+    pr = torch.randn(I, A, device=gpu, generator=g) * 0.4
+    pc = torch.randn(B, A, device=gpu, generator=g) * 0.4
+    feat = torch.randn(I, Fdim, device=gpu, generator=g)
+    w1 = torch.randn(A, device=gpu, generator=g) * 0.3
+    rowptr, col, val, pair_row = _shared_rows(R, I, 90, B, gpu, seed=9)
+    grp_ptr, pair_ids, wg_ptr = native.group_pairs(pair_row, R, 32)
+    assert torch.equal(torch.sort(pair_ids).values, torch.arange(B, device=gpu))
+    counts = torch.bincount(pair_row, minlength=R)
+    assert torch.equal(grp_ptr[1:] - grp_ptr[:-1], counts)
+    assert torch.equal(wg_ptr[1:] - wg_ptr[:-1], (counts + 31) // 32)
+    rows_of_listed = pair_row[pair_ids]
+    assert bool((rows_of_listed[1:] >= rows_of_listed[:-1]).all())          # listed row by row
+    small = native.group_pairs(pair_row[:3000].contiguous(), R, 8)          # single-workgroup path
+    assert torch.equal(torch.sort(small[1]).values, torch.arange(3000, device=gpu))
+    assert torch.equal(small[0][1:] - small[0][:-1], torch.bincount(pair_row[:3000], minlength=R))
+    out_g = native.attn_forward_grouped(native.ATT_MLP, pc, pr, w1, -0.1, rowptr, col, val, pair_row, feat)
+    ex = SparseRatings(rowptr, col, val, I, pair_row=pair_row).expanded()
+    out_p, _ = native.attn_forward(native.ATT_MLP, pc, pr, w1, -0.1, ex.rowptr, ex.col, ex.val, feat)
+    assert_close(out_g, out_p)
+    native.check_oob(gpu)

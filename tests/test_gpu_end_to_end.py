@@ -83,3 +83,48 @@ def test_attention_pipeline_end_to_end(gpu):
     _, _, cand, rated_f, um, _ = prov.collate_interacted_items([(int(u), int(i), r) for u, i, r in batch], False)
     ref = O.attention_ncf_forward(state, cand, rated_f, um)
     assert_close(torch.from_numpy(outs[True][:64]).float().view(-1, 1), ref)
+
+
+def test_hip_graph_replay_matches_eager(gpu):
+    """GraphedForward (deeprecommendation_amd/graphs.py): a captured AttentionNCF step on shared-row ratings and a
+    captured BasicNCF scoring step replay bit-identically to the eager calls, on the captured batch and on new ones
+    (incl. a batch with fewer users / entries than the captured capacity)."""
+    from deeprecommendation_amd.graphs import GraphedForward
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF, SparseRatings
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    torch.manual_seed(3)
+    I, F, B = 300, 48, 256
+    m = AttentionNCF(item_dim=F, item_emb=64, user_emb=64, att_dense=128, mlp_dense_layers=[256, 128]).eval().to(gpu)
+    g = torch.Generator().manual_seed(4)
+    rated = torch.rand(I, F, generator=g).to(gpu)
+
+    def batch(seed, users):
+        gg = torch.Generator().manual_seed(seed)
+        counts = torch.randint(5, 90, (users,), generator=gg)
+        rowptr = torch.zeros(users + 1, dtype=torch.int64)
+        rowptr[1:] = torch.cumsum(counts, 0)
+        col = torch.cat([torch.randperm(I, generator=gg)[:int(c)].sort().values for c in counts]).to(torch.int32)
+        val = torch.randint(1, 11, (int(rowptr[-1]),), generator=gg).float() * 0.5 - 2.9
+        pair_row = torch.randint(0, users, (B,), generator=gg)
+        return torch.rand(B, F, generator=gg).to(gpu), SparseRatings(rowptr.to(gpu), col.to(gpu), val.to(gpu), I, pair_row=pair_row.to(gpu))
+
+    cand0, r0 = batch(1, 12)
+    with torch.no_grad():
+        graphed = GraphedForward(lambda c, rt, um: m(c, rt, um), [cand0, rated, r0])
+        for seed, users in ((1, 12), (2, 12), (3, 7)):      # the last one: fewer rows and entries than captured
+            cand, r = batch(seed, users)
+            if r.col.numel() > r0.col.numel():
+                continue
+            eager = m(cand, rated, r)
+            replay = graphed(cand, rated, r).clone()
+            assert torch.equal(eager, replay)
+    # BasicNCF scoring
+    bm = BasicNCF(item_dim=700, user_dim=3000, item_emb=64, user_emb=64, mlp_dense_layers=[256, 128]).eval().to(gpu)
+    u0 = torch.randint(0, 3000, (4096,), generator=g).to(gpu)
+    i0 = torch.randint(0, 700, (4096,), generator=g).to(gpu)
+    with torch.no_grad():
+        gb = GraphedForward(lambda u, i: bm(u, i), [u0, i0])
+        u1 = torch.randint(0, 3000, (4096,), generator=g).to(gpu)
+        i1 = torch.randint(0, 700, (4096,), generator=g).to(gpu)
+        assert torch.equal(bm(u1, i1), gb(u1, i1).clone())
+        assert torch.equal(bm(u0, i0), gb(u0, i0).clone())
