@@ -253,7 +253,8 @@ __global__ __launch_bounds__(512) void attn_grouped_kernel(const float* __restri
                                                            const int64_t* __restrict__ grp_ptr, const int64_t* __restrict__ pair_ids,
                                                            const int64_t* __restrict__ wg_ptr, int ppw,
                                                            const float* __restrict__ feat, int64_t ldfeat, int Fdim,
-                                                           const float* __restrict__ out_bias, float* __restrict__ out, int64_t ldout) {
+                                                           const float* __restrict__ out_bias, float* __restrict__ out, int64_t ldout,
+                                                           float* __restrict__ wts, const int64_t* __restrict__ wts_off) {
     constexpr int EC = 64;     // entries per tile = lanes
     constexpr int MAXP = 4;    // pairs per wave (ppw <= 32)
     constexpr int NT = 512, NW = NT / 64;   // 8 waves share a tile: 2 workgroups per CU give 4 waves per SIMD
@@ -410,6 +411,8 @@ __global__ __launch_bounds__(512) void attn_grouped_kernel(const float* __restri
             if (k >= np) continue;                         // wave-uniform
             const float ssum = (s2[k][0] + t2[k][0]) + (s2[k][1] + t2[k][1]);
             const float sc = ok ? ssum + (MODE == 0 ? b1 : 0.f) : -INFINITY;
+            if (wts && e0 + lane < end)                    // raw score now, normalised in place after the last tile
+                wts[wts_off[pair_ids[start + wave + NW * k]] + (e0 - beg) + lane] = sc;
             const float mnew = fmaxf(m[k], wave_reduce_dpp(sc, [](float x, float y) { return fmaxf(x, y); }));
             if (mnew == -INFINITY) continue;               // nothing valid so far (wave-uniform): m, l, o stay 0
             const float scale = expf(m[k] - mnew);         // exp(-inf) = 0 on the first valid tile
@@ -450,6 +453,13 @@ __global__ __launch_bounds__(512) void attn_grouped_kernel(const float* __restri
         for (int f = 0; f < FO; ++f) {
             const int ff = f * 64 + lane;
             if (ff < Fdim) out[b * ldout + ff] = o[k][f] * inv + (out_bias ? out_bias[ff] : 0.f);
+        }
+        if (wts) {                                         // attention weights (:224): softmax of the stored raw scores
+            float* wrow = wts + wts_off[b];                // written by this same lane pattern above
+            for (int64_t e = lane; e < end - beg; e += 64) {
+                const float sraw = wrow[e];
+                wrow[e] = (l[k] > 0.f && sraw != -INFINITY) ? expf(sraw - m[k]) * inv : 0.f;
+            }
         }
     }
 }
@@ -626,7 +636,8 @@ extern "C" int ncf_attn_forward_grouped(int mode, const float* pc, int64_t ldpc,
                                         const float* w1, float b1, const int64_t* rowptr, const int32_t* col, const float* val,
                                         int64_t R, int64_t I, const int64_t* grp_ptr, const int64_t* pair_ids,
                                         const int64_t* wg_ptr, int64_t B, int pairs_per_wg, const float* feat, int64_t ldfeat,
-                                        int Fdim, const float* out_bias, float* out, int64_t ldout, ncf_stream_t stream) {
+                                        int Fdim, const float* out_bias, float* out, int64_t ldout, float* wts,
+                                        const int64_t* wts_off, ncf_stream_t stream) {
     if (mode != NCF_ATT_MLP && mode != NCF_ATT_COS)
         return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: mode %d has no LDS-tiled form (use ncf_attn_forward)", mode);
     if (B < 0 || R < 0 || I < 0 || A <= 0 || Fdim <= 0) return fail(NCF_EINVAL, "ncf_attn_forward_grouped: bad sizes");
@@ -634,6 +645,7 @@ extern "C" int ncf_attn_forward_grouped(int mode, const float* pc, int64_t ldpc,
     if (!pc || !pr || !rowptr || !grp_ptr || !pair_ids || !wg_ptr || !feat || !out)
         return fail(NCF_EINVAL, "ncf_attn_forward_grouped: null pointer");
     if (mode == NCF_ATT_MLP && !w1) return fail(NCF_EINVAL, "ncf_attn_forward_grouped: w1 is null");
+    if (wts && !wts_off) return fail(NCF_EINVAL, "ncf_attn_forward_grouped: weights requested without their per-pair offsets");
     if (ldpc < A || ldpr < A || ldfeat < Fdim || ldout < Fdim)
         return fail(NCF_EINVAL, "ncf_attn_forward_grouped: leading dimension smaller than row");
     if (pairs_per_wg < 1 || pairs_per_wg > 32) return fail(NCF_EINVAL, "ncf_attn_forward_grouped: pairs_per_wg must be 1..32");
@@ -655,7 +667,7 @@ extern "C" int ncf_attn_forward_grouped(int mode, const float* pc, int64_t ldpc,
             return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: cannot reserve %zu bytes of LDS", lds);                  \
         }                                                                                                                      \
         hipLaunchKernelGGL((attn_grouped_kernel<M, F, P>), dim3(blocks), dim3(512), lds, s, pc, ldpc, pr, ldpr, A, w1, b1, rowptr, col, val, R, I, \
-                           grp_ptr, pair_ids, wg_ptr, pairs_per_wg, feat, ldfeat, Fdim, out_bias, out, ldout);                 \
+                           grp_ptr, pair_ids, wg_ptr, pairs_per_wg, feat, ldfeat, Fdim, out_bias, out, ldout, wts, wts_off);   \
     } while (0)
 #define LAUNCH_P(M, F) do { if (pieces_per_thread <= 4) LAUNCH1(M, F, 4); else if (pieces_per_thread <= 8) LAUNCH1(M, F, 8); else LAUNCH1(M, F, 16); } while (0)
 #define LAUNCH_F(M) do { if (Fdim <= 64) LAUNCH_P(M, 1); else if (Fdim <= 128) LAUNCH_P(M, 2); else LAUNCH_P(M, 4); } while (0)

@@ -49,7 +49,7 @@ SIGNATURES = {
                                   _c_i64, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "ncf_attn_forward_grouped": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
                                           _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_int, _c_p, _c_p,
-                                          _c_i64, _c_p]),
+                                          _c_i64, _c_p, _c_p, _c_p]),
     "ncf_group_pairs_workspace_bytes": (_c_size, [_c_i64]),
     "ncf_group_pairs": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
     "ncf_edge_softmax_csr": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
@@ -466,10 +466,11 @@ def group_pairs(pair_row: torch.Tensor, n_rows: int, pairs_per_wg: int):
 def attn_forward_grouped(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[torch.Tensor], b1: float,
                          rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, pair_row: torch.Tensor,
                          feat: torch.Tensor, out_bias: Optional[torch.Tensor] = None, pairs_per_wg: Optional[int] = None,
-                         grouping=None):
+                         grouping=None, return_weights: bool = False):
     """LDS-tiled attention for pairs that share rated sets: CSR row ``pair_row[b]`` is pair b's set.  Returns out_feat
-    (B, Fdim); attention weights are not produced (attn_forward on the expanded CSR does that).  ``grouping`` =
-    (group_pairs(pair_row, R, ppw), ppw) computed earlier for this batch skips the sort."""
+    (B, Fdim), or (out_feat, weights) with ``return_weights``: the attention weights in the layout of the expanded
+    per-pair CSR (``SparseRatings.expanded()``).  ``grouping`` = (group_pairs(pair_row, R, ppw), ppw) computed earlier
+    for this batch skips the sort."""
     lib = load_library()
     _dev(pc, "pc")
     B, A, ldpc = _rows2d(pc, "pc")
@@ -489,10 +490,18 @@ def attn_forward_grouped(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Opti
             pairs_per_wg = default_pairs_per_wg(B)
         grp_ptr, pair_ids, wg_ptr = group_pairs(pair_row.to(torch.int64).contiguous(), R, pairs_per_wg)
     out = torch.empty((B, Fdim), dtype=torch.float32, device=pc.device)
+    wts = wts_off = None
+    if return_weights:
+        lens = (rowptr[1:] - rowptr[:-1])[pair_row.to(torch.int64)]
+        wts_off = (torch.cumsum(lens, 0) - lens).contiguous()
+        # expanded nnz without a host sync is not available: size by the upper bound B * (longest row) would be wasteful,
+        # so this one size is read back (return_weights is the explanation / plotting path, not the scoring loop)
+        wts = torch.empty(max(int(lens.sum().item()), 1), dtype=torch.float32, device=pc.device)
     _check(lib.ncf_attn_forward_grouped(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), float(b1), _ptr(rowptr), _ptr(col),
                                         _ptr(val), R, I, _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr), B, int(pairs_per_wg),
-                                        _ptr(feat), ldf, Fdim, _ptr(out_bias), _ptr(out), out.stride(0), _stream(pc)))
-    return out
+                                        _ptr(feat), ldf, Fdim, _ptr(out_bias), _ptr(out), out.stride(0), _ptr(wts), _ptr(wts_off),
+                                        _stream(pc)))
+    return (out, wts) if return_weights else out
 
 
 def l2_normalize_rows(x: torch.Tensor) -> torch.Tensor:

@@ -60,7 +60,13 @@ class SparseRatings:
         return ex
 
     @staticmethod
-    def from_dense(user_matrix: torch.Tensor) -> "SparseRatings":
+    def from_dense(user_matrix: torch.Tensor, share_identical_rows: bool = True) -> "SparseRatings":
+        # the serving call (webapp/backend.py:78-121) passes ONE user's row repeated for every candidate: keep one CSR
+        # row and let every pair point at it (this function reads sizes back to the host anyway)
+        if share_identical_rows and user_matrix.shape[0] > 1 and bool((user_matrix == user_matrix[:1]).all()):
+            one = SparseRatings.from_dense(user_matrix[:1], share_identical_rows=False)
+            one.pair_row = torch.zeros(user_matrix.shape[0], dtype=torch.int64, device=user_matrix.device)
+            return one
         mask = user_matrix != 0  # attention_ncf.py:158 — an entry that is exactly 0 counts as unrated
         rowptr = torch.zeros(user_matrix.shape[0] + 1, dtype=torch.int64, device=user_matrix.device)
         rowptr[1:] = torch.cumsum(mask.sum(dim=1), 0)
@@ -166,12 +172,16 @@ class AttentionNCF(_ScoringMixin, NCF):
             else:
                 mode, w1, b1 = native.ATT_LINEAR, None, 0.0
         shared = ratings.pair_row is not None
-        if (shared and not return_attention_weights and native.attn_grouped_supported(mode, pc.shape[1], proj.shape[1])
+        if (shared and native.attn_grouped_supported(mode, pc.shape[1], proj.shape[1])
                 and ratings.num_pairs >= SparseRatings.GROUPED_MIN_PAIRS_PER_ROW * (ratings.rowptr.numel() - 1)):
             # several pairs per rated set: stage each set once per workgroup in LDS (K3 grouped form)
-            user_emb = native.attn_forward_grouped(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val,
-                                                   ratings.pair_row, proj, out_bias=lu.bias.detach())
-            return self._score(cand_emb, None, user_emb, None)
+            res = native.attn_forward_grouped(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val,
+                                              ratings.pair_row, proj, out_bias=lu.bias.detach(),
+                                              return_weights=return_attention_weights)
+            if return_attention_weights:
+                out = self._score(cand_emb, None, res[0], None)
+                return out, ratings.expanded().to_dense(res[1])
+            return self._score(cand_emb, None, res, None)
         if shared:
             ratings = ratings.expanded()
         user_emb, wts = native.attn_forward(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val, proj,

@@ -223,7 +223,9 @@ int ncf_attn_forward(int mode,
  *   dev_wg_ptr  (n_rows+1):  exclusive prefix sum of ceil(pairs_of_row / pairs_per_wg)     (workgroups per row)
  * — and a workgroup stages a user's rated rows once per 64 entries into LDS for up to pairs_per_wg (1..32) pairs, with
  * an online softmax over the tiles.  Same result as ncf_attn_forward on the expanded per-pair CSR up to fp32 summation
- * order; attention weights are not returned (use ncf_attn_forward for models/attention_ncf.py:224).
+ * order.  dev_weights (optional) receives the attention weights (models/attention_ncf.py:224) in the layout of that
+ * expanded CSR: pair b's weights start at dev_weights[dev_weights_off[b]] and follow its row's entries
+ * (dev_weights_off (B,) = exclusive prefix sum of the row lengths of pair_row[b]).
  * NCF_EUNSUPPORTED (fall back to ncf_attn_forward): mode NCF_ATT_LINEAR, A % 4 != 0, A > 256, Fdim > 256. */
 int ncf_attn_forward_grouped(int mode,
                              const float* dev_pc, int64_t ldpc, const float* dev_pr, int64_t ldpr, int A,
@@ -233,7 +235,8 @@ int ncf_attn_forward_grouped(int mode,
                              const int64_t* dev_grp_ptr, const int64_t* dev_pair_ids, const int64_t* dev_wg_ptr,
                              int64_t B, int pairs_per_wg,
                              const float* dev_feat, int64_t ldfeat, int Fdim, const float* dev_out_bias,
-                             float* dev_out_feat, int64_t ldout, ncf_stream_t stream);
+                             float* dev_out_feat, int64_t ldout,
+                             float* dev_weights, const int64_t* dev_weights_off, ncf_stream_t stream);
 
 /* Builds dev_grp_ptr / dev_pair_ids / dev_wg_ptr of ncf_attn_forward_grouped from dev_pair_row (B,) = the CSR row of
  * each pair (what the dense user_matrix expresses by repeating a user's row, dynamic_datasets.py:24-40): a counting

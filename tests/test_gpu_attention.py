@@ -196,10 +196,15 @@ def test_attention_grouped_equals_per_pair_kernel(native, gpu, mode, A, Fdim, R,
     w1 = torch.randn(A, device=gpu, generator=g) * 0.3
     m = native.ATT_MLP if mode == "mlp" else native.ATT_COS
     rowptr, col, val, pair_row = _shared_rows(R, I, nnz_max, B, gpu, seed=R * 100 + B, bad_cols=(A == 128))
-    out_g = native.attn_forward_grouped(m, pc, pr, w1 if mode == "mlp" else None, 0.25, rowptr, col, val, pair_row, feat,
-                                        out_bias=bias, pairs_per_wg=ppw)
+    out_g, w_g = native.attn_forward_grouped(m, pc, pr, w1 if mode == "mlp" else None, 0.25, rowptr, col, val, pair_row, feat,
+                                             out_bias=bias, pairs_per_wg=ppw, return_weights=True)
+    out_g2 = native.attn_forward_grouped(m, pc, pr, w1 if mode == "mlp" else None, 0.25, rowptr, col, val, pair_row, feat,
+                                         out_bias=bias, pairs_per_wg=ppw)
+    assert torch.equal(out_g, out_g2)                       # asking for the weights does not change the scores
     ex = SparseRatings(rowptr, col, val, I, pair_row=pair_row).expanded()
-    out_p, _ = native.attn_forward(m, pc, pr, w1 if mode == "mlp" else None, 0.25, ex.rowptr, ex.col, ex.val, feat, out_bias=bias)
+    out_p, w_p = native.attn_forward(m, pc, pr, w1 if mode == "mlp" else None, 0.25, ex.rowptr, ex.col, ex.val, feat, out_bias=bias)
+    assert w_g.shape == w_p.shape
+    assert_close(w_g, w_p)                                  # attention weights, expanded-CSR layout (:224)
     # float64 restatement on the CPU
     pcd, prd, fd, w1d = pc.cpu().double(), pr.cpu().double(), feat.cpu().double(), w1.cpu().double()
     ref = torch.zeros(B, Fdim, dtype=torch.float64)
@@ -226,8 +231,8 @@ def test_attention_grouped_equals_per_pair_kernel(native, gpu, mode, A, Fdim, R,
 
 def test_attention_model_takes_the_grouped_path_for_shared_rows(gpu, monkeypatch):
     """AttentionNCF.forward with a shared-row SparseRatings (what SparseDynamicProvider collates) runs the LDS-tiled
-    kernel when users repeat, and agrees with the dense-matrix call and the oracle; with return_attention_weights it
-    falls back to the per-pair kernel and still returns the (B, I) weights."""
+    kernel when users repeat — also with return_attention_weights, whose (B, I) weights come from the same kernel — and
+    agrees with the dense-matrix call and the oracle."""
     from deeprecommendation_amd import native
     from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import SparseRatings
     m, cand, rated, um_rows = _random_case(B=6, I=150, Fdim=40, IE=64, UE=64, A=128, hidden=[256, 128], density=0.4, seed=11)
@@ -248,7 +253,7 @@ def test_attention_model_takes_the_grouped_path_for_shared_rows(gpu, monkeypatch
         out_shared = m(cand.to(gpu), rated.to(gpu), shared)
         out_dense = m(cand.to(gpu), rated.to(gpu), um.to(gpu))
         out_w, att = m(cand.to(gpu), rated.to(gpu), shared, return_attention_weights=True)
-    assert calls == [1]
+    assert calls == [1, 1]
     assert_close(out_shared, ref_out)
     assert_close(out_dense, ref_out)
     assert_close(out_w, ref_out)
