@@ -34,6 +34,46 @@ class GatherConcatFn(torch.autograd.Function):
         return dA, None, dB, None
 
 
+class GatherColumnsFn(torch.autograd.Function):
+    """x[p, :] = W[:, idx[p]] + b for the nn.Linear-layout embedding parameter W [E, U] (basic_ncf.py:25-33): what
+    ``Linear(onehot(idx))`` computes.
+
+    When W is stored id-major (util.row_major_embedding_: the transpose view of a contiguous [U, E] buffer — what
+    BasicNCF / MF construct) this is a ROW gather, and the backward scatters 4·E-byte gradient rows (full-rate atomics)
+    into a zeroed [U, E] buffer whose transpose VIEW is returned: the gradient has the parameter's own strides, so Adam
+    runs elementwise over the raw buffers.  For a plain contiguous [E, U] weight the column kernels are used.  torch's
+    ``W.t()[idx]`` backward goes through a sort and two table-sized copies either way."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, idx):
+        ctx.save_for_backward(idx)
+        ctx.wshape = tuple(weight.shape)
+        ctx.has_bias = bias is not None
+        ctx.row_major = weight.dim() == 2 and weight.t().is_contiguous() and not weight.is_contiguous()
+        if ctx.row_major:
+            x = native.gather_concat(weight.t(), idx)
+            return x if bias is None else x.add_(bias)
+        return native.gather_cols(weight.contiguous(), None if bias is None else bias.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, dX):
+        (idx,) = ctx.saved_tensors
+        dX = dX.contiguous()
+        dW = db = None
+        if ctx.needs_input_grad[0]:
+            E, U = ctx.wshape
+            if ctx.row_major:
+                dT = torch.zeros((U, E), dtype=torch.float32, device=dX.device)
+                native.scatter_add_rows(dX, idx, dT)
+                dW = dT.t()
+            else:
+                dW = torch.zeros((E, U), dtype=torch.float32, device=dX.device)
+                native.scatter_add_cols(dX, idx, dW)
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = native.colsum(dX)
+        return dW, db, None
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu):

@@ -2,6 +2,7 @@
 // gradient dW = dY^T . X as a "TN" MFMA GEMM with an ordered split over the batch, bias gradient, ReLU mask).
 // The data gradient dX = dY . W is the forward row-streaming GEMM with the transposed weight.
 #include "ncf_common.h"
+#include <math.h>
 
 namespace ncf {
 
@@ -26,17 +27,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* pa = A + (ok1 ? n1 : 0);
     const float* pb = Bm + (ok2 ? n2 : 0);
-    for (int64_t m0 = m_lo; m0 < m_hi; m0 += 2 * UNROLL) {
-        float av[UNROLL], bv[UNROLL];
+    // two register sets: the loads of rows m0 + 2*UNROLL.. fly while the MFMAs of rows m0.. run (one or two waves per
+    // SIMD cannot hide a 1-2 us activation fetch behind 8 MFMAs otherwise: measured 131 us -> see DESIGN 4.8)
+    float av[2][UNROLL], bv[2][UNROLL];
+    auto fetch = [&](int set, int64_t m0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t m = m0 + 2 * u + h;
             const bool in = m < m_hi;
-            av[u] = (in && ok1) ? pa[m * lda] : 0.f;
-            bv[u] = (in && ok2) ? pb[m * ldb] : 0.f;
+            av[set][u] = (in && ok1) ? pa[m * lda] : 0.f;
+            bv[set][u] = (in && ok2) ? pb[m * ldb] : 0.f;
         }
+    };
+    fetch(0, m_lo);
+    for (int64_t m0 = m_lo; m0 < m_hi; m0 += 4 * UNROLL) {
+        fetch(1, m0 + 2 * UNROLL);                         // rows past m_hi read as zeros
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < UNROLL; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][u], bv[0][u], acc, 0, 0, 0);
+        fetch(0, m0 + 4 * UNROLL);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][u], bv[1][u], acc, 0, 0, 0);
     }
     // D[i1][i2]: column i2 = lane & 31 (n2), row i1 = acc_row(r, h) (n1)
     float* out = partial + (size_t)blockIdx.z * N1 * N2;
@@ -53,7 +63,15 @@ __global__ void gemm_tn_reduce_kernel(const float* __restrict__ partial, int sli
                                       int N2) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < slices; ++k) s += partial[(size_t)k * n + e];  // slice order: deterministic
+        int k = 0;
+        for (; k + 8 <= slices; k += 8) {                  // 8 independent loads in flight, added in slice order: deterministic
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = partial[(size_t)(k + j) * n + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += t[j];
+        }
+        for (; k < slices; ++k) s += partial[(size_t)k * n + e];
         out[(e / N2) * ldo + (e % N2)] = s;
     }
 }
@@ -101,13 +119,81 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     }
 }
 
+// ---- nn.Linear-layout embeddings (basic_ncf.py:25-33 keeps W as [E, U]: Linear(onehot(i)) = W[:, i] + b) ----
+// out[p, e] = W[e, idx[p]] + b[e]: a COLUMN gather (lanes along e: 64 rows of W, one 4-byte element each)
+__global__ __launch_bounds__(256) void gather_cols_kernel(const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+                                                          const int64_t* __restrict__ idx, int64_t B, int E, int64_t cols,
+                                                          float* __restrict__ out, int64_t ldo, int32_t* oob) {
+    const int64_t total = B * E;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = t / E;
+        const int e = (int)(t - p * E);
+        const int64_t c = idx[p];
+        float v = 0.f;
+        if (c >= 0 && c < cols) v = W[e * ldw + c] + (bias ? bias[e] : 0.f);
+        else if (oob) *oob = 1;
+        out[p * ldo + e] = v;
+    }
+}
+// dW[e, idx[p]] += src[p, e]: the gradient of that gather, straight into the [E, U] layout of the parameter (torch's
+// index_put backward builds it through a sort and two table-sized copies)
+__global__ __launch_bounds__(256) void scatter_add_cols_kernel(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ idx,
+                                                               int64_t B, int E, float* __restrict__ dst, int64_t ldd, int64_t cols,
+                                                               int32_t* oob) {
+    const int64_t total = B * E;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = t / E;
+        const int e = (int)(t - p * E);
+        const int64_t c = idx[p];
+        if (c >= 0 && c < cols) atomicAdd(dst + e * ldd + c, src[p * lds_ + e]);
+        else if (oob) *oob = 1;
+    }
+}
+
+// One pass of torch.optim.Adam's update (train.py:55: Adam(lr, weight_decay); amsgrad / maximize off) over one tensor:
+//   g += wd * p;  m += (1 - b1) * (g - m);  v = b2 * v + (1 - b2) * g * g;
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// — the operation order of torch's own single-tensor path.  7 table passes (read p, g, m, v; write p, m, v) in ONE kernel;
+// torch's default (foreach) path runs ~9 elementwise kernels over the same tensors.
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t n, float lr_over_bc1, float beta1, float beta2,
+                                                        float inv_sqrt_bc2, float eps, float wd) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<const f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<const f32x4*>(m)[i], vv = reinterpret_cast<const f32x4*>(v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gg = wd != 0.f ? gv[j] + wd * pv[j] : gv[j];
+            mv[j] = mv[j] + (1.f - beta1) * (gg - mv[j]);
+            vv[j] = beta2 * vv[j] + (1.f - beta2) * gg * gg;
+            const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
+            pv[j] = pv[j] - lr_over_bc1 * (mv[j] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0) {
+        const int64_t i = 4 * n4 + threadIdx.x;
+        if (i < n) {
+            const float gg = wd != 0.f ? g[i] + wd * p[i] : g[i];
+            const float mm = m[i] + (1.f - beta1) * (gg - m[i]);
+            const float vv = beta2 * v[i] + (1.f - beta2) * gg * gg;
+            m[i] = mm;
+            v[i] = vv;
+            p[i] = p[i] - lr_over_bc1 * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+        }
+    }
+}
+
 }  // namespace ncf
 
 using namespace ncf;
 
 extern "C" size_t ncf_gemm_tn_workspace_bytes(int64_t M, int N1, int N2) {
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
-    int64_t slices = (M + 2047) / 2048;
+    int64_t slices = (M + 1023) / 1024;
     if (slices > 64) slices = 64;
     return (size_t)slices * N1 * N2 * sizeof(float);
 }
@@ -120,10 +206,10 @@ extern "C" int ncf_gemm_tn(const float* A, int64_t lda, const float* Bm, int64_t
     if (!A || !Bm || lda < N1 || ldb < N2) return fail(NCF_EINVAL, "ncf_gemm_tn: bad operand");
     const size_t need = ncf_gemm_tn_workspace_bytes(M, N1, N2);
     if (!workspace || ws_bytes < need) return fail(NCF_EWORKSPACE, "ncf_gemm_tn: workspace %zu < %zu bytes", ws_bytes, need);
-    int64_t slices = (M + 2047) / 2048;
+    int64_t slices = (M + 1023) / 1024;
     if (slices > 64) slices = 64;
     int64_t rps = (M + slices - 1) / slices;
-    rps = (rps + 15) & ~int64_t(15);
+    rps = (rps + 31) & ~int64_t(31);
     dim3 grid((N1 + 63) / 64, (N2 + 63) / 64, (unsigned)slices);
     hipLaunchKernelGGL(gemm_tn_kernel<8>, grid, dim3(256), 0, s, A, lda, Bm, ldb, M, N1, N2, rps, (float*)workspace);
     const int64_t n = (int64_t)N1 * N2;
@@ -174,4 +260,38 @@ extern "C" int ncf_scatter_add_rows(const float* src, int64_t ld_src, const int6
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, idx, B, E, dst, ld_dst, rows, oob);
     return check_launch("ncf_scatter_add_rows");
+}
+
+extern "C" int ncf_gather_cols(const float* W, int64_t ldw, const float* bias, const int64_t* idx, int64_t B, int E, int64_t cols,
+                               float* out, int64_t ldo, int32_t* oob, ncf_stream_t stream) {
+    if (B == 0) return NCF_OK;
+    if (B < 0 || E <= 0 || cols < 0 || !W || !idx || !out || ldw < cols || ldo < E) return fail(NCF_EINVAL, "ncf_gather_cols: bad argument");
+    int64_t blocks = (B * E + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, W, ldw, bias, idx, B, E, cols, out, ldo, oob);
+    return check_launch("ncf_gather_cols");
+}
+
+extern "C" int ncf_scatter_add_cols(const float* src, int64_t ld_src, const int64_t* idx, int64_t B, int E, float* dst, int64_t ld_dst,
+                                    int64_t cols, int32_t* oob, ncf_stream_t stream) {
+    if (B == 0) return NCF_OK;
+    if (B < 0 || E <= 0 || cols < 0 || !src || !idx || !dst || ld_src < E || ld_dst < cols) return fail(NCF_EINVAL, "ncf_scatter_add_cols: bad argument");
+    int64_t blocks = (B * E + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(scatter_add_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, idx, B, E, dst, ld_dst, cols, oob);
+    return check_launch("ncf_scatter_add_cols");
+}
+
+extern "C" int ncf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int64_t step, ncf_stream_t stream) {
+    if (n == 0) return NCF_OK;
+    if (n < 0 || step < 1 || !p || !g || !m || !v) return fail(NCF_EINVAL, "ncf_adam_step: bad argument");
+    if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return fail(NCF_EINVAL, "ncf_adam_step: tensors must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(lr / bc1), beta1, beta2,
+                       (float)(1.0 / sqrt(bc2)), eps, weight_decay);
+    return check_launch("ncf_adam_step");
 }

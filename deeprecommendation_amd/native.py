@@ -64,6 +64,10 @@ SIGNATURES = {
     "ncf_relu_backward": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_p]),
     "ncf_scatter_add_rows": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_l2_normalize_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p]),
+    "ncf_gather_cols": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
+    "ncf_scatter_add_cols": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "ncf_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                               ctypes.c_float, _c_i64, _c_p]),
 }
 
 _lib = None
@@ -607,3 +611,39 @@ def scatter_add_rows(src: torch.Tensor, idx: Optional[torch.Tensor], dst: torch.
         raise ValueError("row widths disagree")
     _check(lib.ncf_scatter_add_rows(_ptr(src), lds, _ptr(_idx(idx)), B, E, _ptr(dst), ldd, rows, _ptr(_oob_flag(src.device)), _stream(src)))
     return dst
+
+
+# ------------------------------------------------------------------ training step: Linear-layout embeddings, Adam
+def gather_cols(W: torch.Tensor, bias: Optional[torch.Tensor], idx: torch.Tensor) -> torch.Tensor:
+    """out[p, :] = W[:, idx[p]] + bias  (W is the nn.Linear weight [E, U])."""
+    lib = load_library()
+    _dev(W, "W")
+    E, U, ldw = _rows2d(W, "W")
+    idx = _idx(idx)
+    out = torch.empty((idx.numel(), E), dtype=torch.float32, device=W.device)
+    _check(lib.ncf_gather_cols(_ptr(W), ldw, _ptr(bias), _ptr(idx), idx.numel(), E, U, _ptr(out), out.stride(0) if idx.numel() else E,
+                               _ptr(_oob_flag(W.device)), _stream(W)))
+    return out
+
+
+def scatter_add_cols(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst[:, idx[p]] += src[p, :]  (dst is [E, U])."""
+    lib = load_library()
+    _dev(src, "src")
+    B, E, lds = _rows2d(src, "src")
+    E2, U, ldd = _rows2d(dst, "dst")
+    if E != E2:
+        raise ValueError("scatter_add_cols: widths disagree")
+    _check(lib.ncf_scatter_add_cols(_ptr(src), lds, _ptr(_idx(idx)), B, E, _ptr(dst), ldd, U, _ptr(_oob_flag(src.device)), _stream(src)))
+    return dst
+
+
+def adam_step_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
+               weight_decay: float, step: int):
+    lib = load_library()
+    _dev(p, "p")
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
+            raise ValueError("adam_step_: contiguous fp32 tensors of one size")
+    _check(lib.ncf_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                             float(weight_decay), int(step), _stream(p)))

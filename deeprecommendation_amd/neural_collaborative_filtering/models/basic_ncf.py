@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from ... import native
-from ..util import build_MLP_layers, mlp_linears, params_version, require_gpu, use_native
+from ..util import build_MLP_layers, mlp_linears, params_version, require_gpu, row_major_embedding_, use_native
 from .base import NCF
 
 
@@ -53,6 +53,15 @@ class _ScoringMixin:
                 # row i = W[:, i] + b : exactly what Linear(onehot(i)) computes (one fp32 rounding)
                 cache[name] = (lin.weight.detach().t().contiguous() + lin.bias.detach()).to(self.scoring_dtype).contiguous()
         return cache[name]
+
+    def _dense_weight(self, name: str, lin: nn.Linear) -> torch.Tensor:
+        """Row-contiguous [E, num_ids] copy of an embedding weight for the dense-profile GEMM (the parameter itself is
+        stored id-major, util.row_major_embedding_); cached per weight version."""
+        cache = self._refresh()
+        key = "dense_w::" + name
+        if key not in cache:
+            cache[key] = lin.weight.detach().contiguous()
+        return cache[key]
 
     def _packed_mlp(self, name: str = "MLP"):
         cache = self._refresh()
@@ -116,8 +125,8 @@ class BasicNCF(_ScoringMixin, NCF):
             mlp_dense_layers = [256, 128]
         self.kwargs = {'item_dim': item_dim, 'user_dim': user_dim, 'item_emb': item_emb, 'user_emb': user_emb,
                        'mlp_dense_layers': mlp_dense_layers, 'dropout_rate': dropout_rate}
-        self.item_embeddings = nn.Sequential(nn.Linear(item_dim, item_emb))
-        self.user_embeddings = nn.Sequential(nn.Linear(user_dim, user_emb))
+        self.item_embeddings = nn.Sequential(row_major_embedding_(nn.Linear(item_dim, item_emb)))
+        self.user_embeddings = nn.Sequential(row_major_embedding_(nn.Linear(user_dim, user_emb)))
         self.MLP = build_MLP_layers(item_emb + user_emb, mlp_dense_layers, dropout_rate=dropout_rate)
 
     def get_model_parameters(self) -> dict:
@@ -132,22 +141,24 @@ class BasicNCF(_ScoringMixin, NCF):
             return self._score(self._table("user", self.user_embeddings[0]), X_user.contiguous(),
                                self._table("item", self.item_embeddings[0]), X_item.contiguous())
         ue, ie = self.user_embeddings[0], self.item_embeddings[0]
-        u = native.linear(X_user.float().contiguous(), ue.weight.detach(), ue.bias.detach())
-        i = native.linear(X_item.float().contiguous(), ie.weight.detach(), ie.bias.detach())
+        u = native.linear(X_user.float().contiguous(), self._dense_weight("user", ue), ue.bias.detach())
+        i = native.linear(X_item.float().contiguous(), self._dense_weight("item", ie), ie.bias.detach())
         return self._score(u, None, i, None)  # cat(user, item): basic_ncf.py:40
 
     def _forward_train(self, X_user, X_item, indexed):
         """Training step (dropout active, autograd recording).  On CUDA tensors the gather and the Linear(+ReLU) layers run
         forward AND backward on the HIP kernels through deeprecommendation_amd.autograd; on CPU it is plain torch."""
         if X_user.is_cuda and not getattr(self, "train_with_torch_ops", False):
-            from ...autograd import LinearFn, mlp_train
+            from ...autograd import GatherColumnsFn, LinearFn, mlp_train
             ue, ie = self.user_embeddings[0], self.item_embeddings[0]
             if indexed:
                 # The parameters live in nn.Linear layout [E, U] (checkpoint compatibility), so a training step gathers
-                # COLUMNS of W; materialising T = W^T + b every step for the row-gather kernel costs two full-table
-                # passes (measured 13.6 ms vs 3.9 ms per step at 1 M users).  torch's strided index + its index_put
-                # backward touch only the B requested columns; the MLP runs on the HIP blocks.
-                x = torch.cat((ue.weight.t()[X_user] + ue.bias, ie.weight.t()[X_item] + ie.bias), dim=1)
+                # COLUMNS of W (materialising T = W^T + b every step for the row-gather kernel costs two full-table
+                # passes: 13.6 ms per step at 1 M users).  GatherColumnsFn reads the B columns and, backward, scatters the
+                # gradient straight into a zeroed [E, U] tensor; torch's `W.t()[idx]` backward sorts the ids and makes two
+                # table-sized copies on the way (1.3 ms of a 3.9 ms step).
+                x = torch.cat((GatherColumnsFn.apply(ue.weight, ue.bias, X_user.contiguous()),
+                               GatherColumnsFn.apply(ie.weight, ie.bias, X_item.contiguous())), dim=1)
             else:
                 x = torch.cat((LinearFn.apply(X_user.float(), ue.weight, ue.bias, False),
                                LinearFn.apply(X_item.float(), ie.weight, ie.bias, False)), dim=1)

@@ -3,7 +3,7 @@ import torch
 from torch import nn
 
 from ... import native
-from ..util import require_gpu, use_native
+from ..util import require_gpu, row_major_embedding_, use_native
 from .base import NCF
 from .basic_ncf import _ScoringMixin
 
@@ -14,8 +14,8 @@ class MF(_ScoringMixin, NCF):
     def __init__(self, item_dim, user_dim, item_emb=128, user_emb=128):
         super().__init__()
         self.kwargs = {'item_dim': item_dim, 'user_dim': user_dim, 'item_emb': item_emb, 'user_emb': user_emb}
-        self.item_embeddings = nn.Sequential(nn.Linear(item_dim, item_emb))
-        self.user_embeddings = nn.Sequential(nn.Linear(user_dim, user_emb))
+        self.item_embeddings = nn.Sequential(row_major_embedding_(nn.Linear(item_dim, item_emb)))
+        self.user_embeddings = nn.Sequential(row_major_embedding_(nn.Linear(user_dim, user_emb)))
 
     def get_model_parameters(self) -> dict:
         return self.kwargs
@@ -34,6 +34,6 @@ class MF(_ScoringMixin, NCF):
             return native.gather_dot(self._table("user", self.user_embeddings[0]), X_user.contiguous(),
                                      self._table("item", self.item_embeddings[0]), X_item.contiguous())
         ue, ie = self.user_embeddings[0], self.item_embeddings[0]
-        u = native.linear(X_user.float().contiguous(), ue.weight.detach(), ue.bias.detach())
-        i = native.linear(X_item.float().contiguous(), ie.weight.detach(), ie.bias.detach())
+        u = native.linear(X_user.float().contiguous(), self._dense_weight("user", ue), ue.bias.detach())
+        i = native.linear(X_item.float().contiguous(), self._dense_weight("item", ie), ie.bias.detach())
         return native.gather_dot(u, None, i, None, B=u.shape[0])

@@ -17,6 +17,21 @@ def build_MLP_layers(input_size, layer_sizes: list, dropout_rate, output_size=1)
     return nn.Sequential(*mods)
 
 
+def row_major_embedding_(lin: nn.Linear) -> nn.Linear:
+    """Re-lay the weight of an embedding ``Linear(num_ids, E)`` in place: same logical tensor ``[E, num_ids]`` (state_dict
+    keys, shapes and values are unchanged: reference checkpoints load and save as before), but stored id-major — the
+    parameter is the transpose VIEW of a contiguous ``[num_ids, E]`` buffer.  ``Linear(onehot(i)) = W[:, i] + b`` is then
+    a contiguous 4·E-byte row: a training step gathers rows, scatters gradient rows (full-rate 256-byte atomics instead of
+    E scattered 4-byte ones) and Adam runs elementwise over the buffers, with no table-sized transpose anywhere."""
+    w = lin.weight.data
+    lin.weight = nn.Parameter(w.t().contiguous().t(), requires_grad=lin.weight.requires_grad)
+    return lin
+
+
+def is_row_major_embedding(weight: torch.Tensor) -> bool:
+    return weight.dim() == 2 and weight.t().is_contiguous() and not weight.is_contiguous()
+
+
 def mlp_linears(seq: nn.Sequential):
     """The Linear modules of a build_MLP_layers Sequential, in order."""
     return [m for m in seq if isinstance(m, nn.Linear)]

@@ -276,6 +276,21 @@ int ncf_relu_backward(float* dev_dY, int64_t ld_dY, const float* dev_Y, int64_t 
 int ncf_scatter_add_rows(const float* dev_src, int64_t ld_src, const int64_t* dev_idx, int64_t B, int E,
                          float* dev_dst, int64_t ld_dst, int64_t rows, int32_t* dev_oob_flag, ncf_stream_t stream);
 
+/* nn.Linear-layout embeddings (models/basic_ncf.py:25-33: the parameter is W [E, U], Linear(onehot(i)) = W[:, i] + b):
+ *   ncf_gather_cols       out[p, e]      = W[e, idx[p]] + b[e]          (forward of a training step: no W^T + b table)
+ *   ncf_scatter_add_cols  dW[e, idx[p]] += src[p, e]                    (its gradient, straight into the [E, U] layout)
+ * An out-of-range idx reads zeros / is dropped and sets the sticky flag. */
+int ncf_gather_cols(const float* dev_W, int64_t ldw, const float* dev_bias, const int64_t* dev_idx, int64_t B, int E,
+                    int64_t n_cols, float* dev_out, int64_t ldo, int32_t* dev_oob_flag, ncf_stream_t stream);
+int ncf_scatter_add_cols(const float* dev_src, int64_t ld_src, const int64_t* dev_idx, int64_t B, int E,
+                         float* dev_dst, int64_t ld_dst, int64_t n_cols, int32_t* dev_oob_flag, ncf_stream_t stream);
+
+/* One torch.optim.Adam update (train.py:55; amsgrad and maximize off) of ONE tensor in a single pass:
+ *   g' = g + weight_decay * p;  m += (1 - beta1)(g' - m);  v = beta2 v + (1 - beta2) g'^2;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)          (step counts from 1) */
+int ncf_adam_step(float* dev_p, const float* dev_g, float* dev_m, float* dev_v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, ncf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

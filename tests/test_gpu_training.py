@@ -115,3 +115,79 @@ def test_gather_concat_autograd_block(gpu):
     (out * wgt.to(gpu)).sum().backward()
     assert float((tag.grad.cpu() - ga).abs().max()) <= 1e-5 * float(ga.abs().max())
     assert float((tbg.grad.cpu() - gb).abs().max()) <= 1e-5 * float(gb.abs().max())
+
+
+def test_gather_columns_autograd_block(gpu):
+    """GatherColumnsFn (Linear-layout embedding parameter W [E, U]) == torch's `W.t()[idx] + b` forward (bit-exact) and
+    backward (float atomics: duplicates of an id add in any order -> 1e-6), incl. repeated ids."""
+    from deeprecommendation_amd.autograd import GatherColumnsFn
+    g = torch.Generator().manual_seed(0)
+    E, U, B = 64, 500, 3000
+    W0 = torch.randn(E, U, generator=g)
+    b0 = torch.randn(E, generator=g)
+    idx = torch.randint(0, U, (B,), generator=g)
+    idx[:200] = 7                                          # a hot id
+    dY = torch.randn(B, E, generator=g)
+    W1, b1 = W0.clone().to(gpu).requires_grad_(), b0.clone().to(gpu).requires_grad_()
+    y1 = GatherColumnsFn.apply(W1, b1, idx.to(gpu))
+    y1.backward(dY.to(gpu))
+    W2, b2 = W0.clone().requires_grad_(), b0.clone().requires_grad_()
+    y2 = W2.t()[idx] + b2
+    y2.backward(dY)
+    assert torch.equal(y1.detach().cpu(), y2.detach())
+    assert float((W1.grad.cpu() - W2.grad).abs().max()) <= 1e-6 * float(W2.grad.abs().max()) + 1e-6
+    assert float((b1.grad.cpu() - b2.grad).abs().max()) <= 1e-5 * float(b2.grad.abs().max())
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_fused_adam_matches_torch_adam(gpu, wd):
+    """deeprecommendation_amd.optim.FusedAdam (one kernel per tensor) follows torch.optim.Adam (train.py:55) step for
+    step: 6 updates on tensors of odd sizes (vector body + scalar tail), with and without weight decay."""
+    from deeprecommendation_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(64, 1001), (7,), (256, 128), (1,)]
+    p_ref = [torch.randn(s, generator=g).requires_grad_() for s in shapes]
+    p_hip = [p.detach().clone().to(gpu).requires_grad_() for p in p_ref]
+    o_ref = torch.optim.Adam(p_ref, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    o_hip = FusedAdam(p_hip, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    for step in range(6):
+        for pr, ph in zip(p_ref, p_hip):
+            gr = torch.randn(pr.shape, generator=g) * (0.0 if step == 3 else 1.0)   # a step with zero gradient still moves p
+            pr.grad = gr.clone()
+            ph.grad = gr.clone().to(gpu)
+        o_ref.step()
+        o_hip.step()
+        for pr, ph in zip(p_ref, p_hip):
+            assert float((ph.detach().cpu() - pr.detach()).abs().max()) <= 2e-6 * float(pr.detach().abs().max()) + 1e-7
+
+
+def test_training_steps_with_fused_adam_track_torch(gpu):
+    """Five BasicNCF training steps (no dropout) on the HIP blocks + FusedAdam follow the same steps on torch ops +
+    torch.optim.Adam: losses within 1e-5 relative."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    from deeprecommendation_amd.optim import FusedAdam
+    torch.manual_seed(5)
+    U, I, B = 900, 400, 2048
+    base = BasicNCF(item_dim=I, user_dim=U, item_emb=64, user_emb=64, mlp_dense_layers=[256, 128], dropout_rate=None)
+    state = {k: v.clone() for k, v in base.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    batches = [(torch.randint(0, U, (B,), generator=g), torch.randint(0, I, (B,), generator=g), torch.rand(B, 1, generator=g) * 5)
+               for _ in range(5)]
+    losses = {}
+    for mode in ("hip", "torch"):
+        m = BasicNCF(item_dim=I, user_dim=U, item_emb=64, user_emb=64, mlp_dense_layers=[256, 128], dropout_rate=None)
+        m.load_state_dict(state)
+        m.to(gpu).train()
+        m.train_with_torch_ops = mode == "torch"
+        opt = FusedAdam(m.parameters(), lr=1e-3) if mode == "hip" else torch.optim.Adam(m.parameters(), lr=1e-3)
+        out = []
+        for u, i, y in batches:
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.mse_loss(m(u.to(gpu), i.to(gpu)), y.to(gpu), reduction="sum")
+            loss.backward()
+            opt.step()
+            out.append(float(loss))
+        losses[mode] = out
+    for a, b in zip(losses["hip"], losses["torch"]):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    assert losses["hip"][-1] < losses["hip"][0]
