@@ -215,7 +215,10 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for k in range(args.warmup):
+        # untimed: the requested warm-up steps, topped up to >= 300 so that the chip's clock has settled on this kernel
+        # before the timed region (DVFS takes milliseconds to settle; measured: 50 timed steps straight after 5 warm-ups
+        # read 805 M pairs/s, after the settling 905 M) — the timed region is exactly --steps steps either way
+        for k in range(max(args.warmup, 300)):
             out = step(k)
         barrier()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -239,7 +242,7 @@ def main():
     tu, ti = model._table("user", model.user_embeddings[0]), model._table("item", model.item_embeddings[0])
     outbuf = torch.empty((B, 1), dtype=torch.float32, device=device)
     reps = 100
-    for k in range(5):
+    for k in range(60):
         native.score_fused(tu, batches[k % N_BATCHES][0], ti, batches[k % N_BATCHES][1], packed, out=outbuf)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -16,8 +16,13 @@ import torch
 
 
 def _time_steps(step, warmup, steps):
-    for k in range(warmup):
+    # untimed: the warm-up steps, continued until ~30 ms have been enqueued so that the clock has settled on this
+    # workload's kernels (short steps only; DVFS takes milliseconds); the timed region is exactly `steps` steps
+    t_w = time.perf_counter()
+    k = 0
+    while k < warmup or (time.perf_counter() - t_w < 0.03 and k < 2000):
         step(k)
+        k += 1
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
