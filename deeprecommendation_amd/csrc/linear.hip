@@ -9,6 +9,8 @@
 // which keeps every MFMA fed by one 16-byte LDS read per operand per 4 k-steps.
 // N <= 8 goes to a row-dot kernel (one 16-lane group per output element) instead of wasting a 64-wide tile.
 #include "ncf_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace ncf {
 
@@ -231,6 +233,93 @@ __global__ __launch_bounds__(256) void linear_rs_kernel(const float* __restrict_
     }
 }
 
+// Row-streaming GEMM with the A rows staged through LDS in full lines (an alternative to linear_rs_kernel's A fragments
+// read straight from global memory, 32 rows x 32 bytes per wave-instruction; chosen by shape in launch_rs_nt, where the
+// measurements are).  Here a 256-thread workgroup (4 waves x 32 rows) copies its 128 rows, 128 k-columns at a time, with whole
+// 512-byte row reads (32 lanes x 16 B) into LDS (row stride KC + 4 floats: the fragment read `row i, bytes 32q + 16h` is
+// then a conflict-free ds_read_b128), all loads of a chunk in flight at once; two workgroups per CU overlap one's copy
+// with the other's MFMAs.  W fragments still come from L2 (they are small and shared by every wave).  Same k order per
+// output as linear_rs_kernel<NT, 1>: bit-identical results.
+template <int NT, bool RELU>
+__global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                         int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
+                                                         int64_t ldc, int64_t M, int K) {
+    constexpr int KC = 128, AS = KC + 4, ROWS = 128;
+    __shared__ __attribute__((aligned(16))) float at[ROWS * AS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const float* wrow[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (int64_t)(32 * nt + i) * ldw + 4 * h;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const float* myrow = at + (32 * wave + i) * AS + 4 * h;
+
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        const int kc = K - k0 < KC ? K - k0 : KC;          // multiple of 8 (host check)
+        const int c4n = kc / 4;                            // 16-byte pieces per row in this chunk
+        if (k0) __syncthreads();                           // the previous chunk has been consumed
+        for (int idx = tid; idx < ROWS * c4n; idx += 256) {
+            const int r = idx / c4n, c = idx % c4n;
+            const int64_t gm = row0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gm < M) v = *reinterpret_cast<const f32x4*>(A + gm * lda + k0 + 4 * c);
+            *reinterpret_cast<f32x4*>(at + r * AS + 4 * c) = v;
+        }
+        __syncthreads();
+        const int Q = kc / 8;
+        f32x4 w0[NT], w1[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) w0[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt] + k0);
+        for (int q = 0; q < Q; q += 2) {                   // two-stage register pipeline on the W fragments
+            const bool has1 = q + 1 < Q;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w1[nt] = has1 ? *reinterpret_cast<const f32x4u*>(wrow[nt] + k0 + 8 * (q + 1)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(myrow + 8 * q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], w0[nt][j], acc[nt], 0, 0, 0);
+            if (has1) {
+                const bool has2 = q + 2 < Q;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w0[nt] = has2 ? *reinterpret_cast<const f32x4u*>(wrow[nt] + k0 + 8 * (q + 2)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(myrow + 8 * (q + 1));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], w1[nt][j], acc[nt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = 32 * nt + i;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t gm = row0 + 32 * wave + acc_row(r, h);
+            if (gm < M) {
+                float v = acc[nt][r] + bv;
+                if (RELU) v = fmaxf(v, 0.f);
+                C[gm * ldc + n] = v;
+            }
+        }
+    }
+}
+
+template <int NT>
+static void launch_lds(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                       int64_t M, int K, bool relu, hipStream_t s) {
+    const unsigned blocks = (unsigned)((M + 127) / 128);
+    if (relu) hipLaunchKernelGGL((linear_lds_kernel<NT, true>), dim3(blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
+    else hipLaunchKernelGGL((linear_lds_kernel<NT, false>), dim3(blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
+}
+
 template <int NT, int KS>
 static void launch_rs(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                       int64_t M, int K, bool relu, hipStream_t s, int col_blocks = 1) {
@@ -244,6 +333,18 @@ template <int NT>
 static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                          int64_t M, int K, bool relu, hipStream_t s) {
     const int64_t tiles = (M + 31) / 32;
+#ifndef NCF_LINEAR_LDS
+#define NCF_LINEAR_LDS 1
+#endif
+    // A staged through LDS in full lines: measured against the global-fragment kernel (tools/ab_linear.py, M = 65 536)
+    // K = 256 -> N = 128: 64.6 vs 88.3 us, K = 64 -> N = 128: 26.2 vs 55.1 us (the shapes where that kernel splits K);
+    // slower elsewhere (K = 128: 91 vs 83 us; 1.1 M x 128 x 128: 654 vs 595 us — both kernels are bound by the
+    // fragment-shaped W loads, 32 rows x 32 B per instruction, not by A), so it is used for those two shape classes only.
+    const char* force = getenv("NCF_LINEAR_KERNEL");      // "rs" / "lds": A/B and tests; unset: by shape
+    const bool lds_ok = K % 8 == 0 && lda % 4 == 0 && aligned16(A);
+    const bool lds_wins = M >= 16384 && M <= 262144 && ((K >= 256 && NT <= 4) || K <= 64);
+    if (lds_ok && (force ? !strcmp(force, "lds") : (NCF_LINEAR_LDS && lds_wins)))
+        return launch_lds<NT>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
     if constexpr (NT <= 4) {
         // Skinny and deep (the 4096 x 2094 -> 64 candidate Linear of AttentionNCF: 128 row tiles): one 32-column block
         // per workgroup so that tiles * NT workgroups share the chip — the rows of A are re-read once per column block

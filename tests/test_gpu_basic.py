@@ -423,3 +423,20 @@ def test_small_batch_kernel_is_bit_identical_to_main_kernel(native, gpu, E, hidd
     assert torch.equal(big, small)
     ref = c_oracle.score_fused_f32(ta, tb, ia, ib, ws, bs)
     assert torch.equal(big.cpu(), ref)
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(20000, 256, 128, True), (16500, 64, 128, False), (300, 40, 64, True), (16384, 128, 256, False)])
+@pytest.mark.parametrize("kernel", ["rs", "lds"])
+def test_linear_kernels_agree_with_float64(native, gpu, monkeypatch, M, K, N, relu, kernel):
+    """Both row-streaming GEMM forms (A fragments from global memory / staged through LDS) against a float64 product,
+    incl. a ragged last row block and a shape the LDS form declines (K % 8 != 0 falls back by itself)."""
+    monkeypatch.setenv("NCF_LINEAR_KERNEL", kernel)
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    out = native.linear_act(x.to(gpu), w.to(gpu), b.to(gpu), relu)
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = torch.relu(ref)
+    assert_close(out, ref.float())
