@@ -177,16 +177,52 @@ __global__ __launch_bounds__(256) void linear_rs_kernel(const float* __restrict_
     const int Q = K / 8;
     const int qlo = (int)((int64_t)ks * Q / KS), qhi = (int)((int64_t)(ks + 1) * Q / KS);
     if (tile_ok) {
-        RsFrag<NT> f0, f1;
-        int q = qlo;
-        if (q < qhi) rs_load<NT>(f0, arow, wrow, q);
-        for (; q + 1 < qhi; q += 2) {  // two-stage register pipeline: the next group's loads fly under this group's MFMAs
-            rs_load<NT>(f1, arow, wrow, q + 1);
-            rs_mma<NT>(f0, acc);
-            if (q + 2 < qhi) rs_load<NT>(f0, arow, wrow, q + 2);
-            rs_mma<NT>(f1, acc);
+      if (qhi > qlo) {
+        // A fragments run PD k-steps ahead of the MFMAs in a register ring: the A rows stream from HBM, and with the
+        // one-step-ahead pipeline this kernel had, a CU kept 8 KB in flight — 2 MB chip-wide, i.e. 1.9 TB/s at ~1 us of
+        // latency, which is exactly what it measured (595 us on 1.1 M x 128 x 128).  W fragments (L2 hits) stay one step
+        // ahead.  Steps past qhi load zeros and add nothing; the k order per output is unchanged.
+        constexpr int PD = NT >= 2 ? 8 : 16;
+        f32x4 ar[PD];
+        // no branch around a load (hipcc would wait vmcnt(0) per element): the address is clamped, the VALUE is selected
+        const int qlast = qhi > qlo ? qhi - 1 : qlo;
+        auto load_a = [&](int q) {
+            const f32x4 v = *reinterpret_cast<const f32x4u*>(arow + 8 * (q < qhi ? q : qlast));
+            const bool in = q < qhi;
+            return f32x4{in ? v[0] : 0.f, in ? v[1] : 0.f, in ? v[2] : 0.f, in ? v[3] : 0.f};
+        };
+        auto load_w = [&](f32x4 (&w)[NT], int q) {      // a step past qhi multiplies this by A = 0
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt] + 8 * (q < qhi ? q : qlast));
+        };
+#pragma unroll
+        for (int d = 0; d < PD; ++d) ar[d] = load_a(qlo + d);
+        f32x4 w0[NT], w1[NT];
+        load_w(w0, qlo);
+        for (int qb = qlo; qb < qhi; qb += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; d += 2) {
+                load_w(w1, qb + d + 1);
+                {
+                    const f32x4 a = ar[d];
+                    ar[d] = load_a(qb + d + PD);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w0[nt][j], acc[nt], 0, 0, 0);
+                }
+                load_w(w0, qb + d + 2);
+                {
+                    const f32x4 a = ar[d + 1];
+                    ar[d + 1] = load_a(qb + d + 1 + PD);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w1[nt][j], acc[nt], 0, 0, 0);
+                }
+            }
         }
-        if (q < qhi) rs_mma<NT>(f0, acc);
+      }
         if ((K & 7) && ks == KS - 1) {  // ragged tail of K: guarded scalar loads, zero fill
             RsFrag<NT> t;
 #pragma unroll
@@ -233,91 +269,105 @@ __global__ __launch_bounds__(256) void linear_rs_kernel(const float* __restrict_
     }
 }
 
-// Row-streaming GEMM with the A rows staged through LDS in full lines (an alternative to linear_rs_kernel's A fragments
-// read straight from global memory, 32 rows x 32 bytes per wave-instruction; chosen by shape in launch_rs_nt, where the
-// measurements are).  Here a 256-thread workgroup (4 waves x 32 rows) copies its 128 rows, 128 k-columns at a time, with whole
-// 512-byte row reads (32 lanes x 16 B) into LDS (row stride KC + 4 floats: the fragment read `row i, bytes 32q + 16h` is
-// then a conflict-free ds_read_b128), all loads of a chunk in flight at once; two workgroups per CU overlap one's copy
-// with the other's MFMAs.  W fragments still come from L2 (they are small and shared by every wave).  Same k order per
-// output as linear_rs_kernel<NT, 1>: bit-identical results.
+// Persistent form of linear_rs_kernel<NT, 1> for tall problems (K % 64 == 0): a wave walks over its row tiles and the
+// A-fragment ring runs PD = 8 k-steps ahead ACROSS tile boundaries, so the next tile's first fragments are in flight
+// while the current tile finishes and stores.  In the one-tile-per-wave form every tile paid workgroup dispatch, pointer
+// set-up and a cold first fetch (~2 us exposed against ~8 us of MFMAs, measured 571 us on 1.1 M x 128 x 128 where the
+// MFMAs alone are 229 us and HBM 225 us); neither deeper prefetch inside a tile (571 vs 586 us), nor staging A or A and W
+// through LDS (654 / 702 us) moved it — see tools/ab_linear.py.  Same k order per output: bit-identical results.
 template <int NT, bool RELU>
-__global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void linear_rsp_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                          int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
                                                          int64_t ldc, int64_t M, int K) {
-    constexpr int KC = 128, AS = KC + 4, ROWS = 128;
-    __shared__ __attribute__((aligned(16))) float at[ROWS * AS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PD = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int64_t tiles = (M + 31) / 32;
+    const int64_t first = (int64_t)blockIdx.x * 4 + wave, stride = (int64_t)gridDim.x * 4;
+    if (first >= tiles) return;
+    const int64_t mine = (tiles - first + stride - 1) / stride;     // row tiles of this wave
+    const int Q = K / 8;                                            // multiple of PD (host check)
+    const int64_t S = mine * Q;                                     // k-steps of this wave's stream
     const float* wrow[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (int64_t)(32 * nt + i) * ldw + 4 * h;
-    f32x16 acc[NT];
+    float bv[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-    const float* myrow = at + (32 * wave + i) * AS + 4 * h;
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = bias ? bias[32 * nt + i] : 0.f;
 
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        const int kc = K - k0 < KC ? K - k0 : KC;          // multiple of 8 (host check)
-        const int c4n = kc / 4;                            // 16-byte pieces per row in this chunk
-        if (k0) __syncthreads();                           // the previous chunk has been consumed
-        for (int idx = tid; idx < ROWS * c4n; idx += 256) {
-            const int r = idx / c4n, c = idx % c4n;
-            const int64_t gm = row0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gm < M) v = *reinterpret_cast<const f32x4*>(A + gm * lda + k0 + 4 * c);
-            *reinterpret_cast<f32x4*>(at + r * AS + 4 * c) = v;
-        }
-        __syncthreads();
-        const int Q = kc / 8;
+    // stream position p -> (tile first + (p / Q) * stride, k-step p % Q); past the end: the last step again (its MFMAs
+    // never run: the loops below stop at S)
+    auto a_at = [&](int64_t p) {
+        if (p >= S) p = S - 1;
+        const int64_t t = first + (p / Q) * stride;
+        const int64_t m = t * 32 + i;
+        return *reinterpret_cast<const f32x4u*>(A + (m < M ? m : (M - 1)) * lda + 4 * h + 8 * (p % Q));
+    };
+    f32x4 ar[PD];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) ar[d] = a_at(d);
+
+    for (int64_t tk = 0; tk < mine; ++tk) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         f32x4 w0[NT], w1[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) w0[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt] + k0);
-        for (int q = 0; q < Q; q += 2) {                   // two-stage register pipeline on the W fragments
-            const bool has1 = q + 1 < Q;
+        for (int nt = 0; nt < NT; ++nt) w0[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt]);
+        const int64_t p0 = tk * Q;
+        for (int qb = 0; qb < Q; qb += PD) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) w1[nt] = has1 ? *reinterpret_cast<const f32x4u*>(wrow[nt] + k0 + 8 * (q + 1)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(myrow + 8 * q);
+            for (int d = 0; d < PD; d += 2) {
+                const int q = qb + d;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt) w1[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt] + 8 * (q + 1));   // q + 1 < Q: Q is even
+                {
+                    const f32x4 a = ar[d];
+                    ar[d] = a_at(p0 + q + PD);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], w0[nt][j], acc[nt], 0, 0, 0);
-            if (has1) {
-                const bool has2 = q + 2 < Q;
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) w0[nt] = has2 ? *reinterpret_cast<const f32x4u*>(wrow[nt] + k0 + 8 * (q + 2)) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(myrow + 8 * (q + 1));
+                        for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w0[nt][j], acc[nt], 0, 0, 0);
+                }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt) w0[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt] + 8 * (q + 2 < Q ? q + 2 : 0));
+                {
+                    const f32x4 a = ar[d + 1];
+                    ar[d + 1] = a_at(p0 + q + 1 + PD);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], w1[nt][j], acc[nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w1[nt][j], acc[nt], 0, 0, 0);
+                }
             }
         }
-    }
+        const int64_t tile = first + tk * stride;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = 32 * nt + i;
-        const float bv = bias ? bias[n] : 0.f;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = 32 * nt + i;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t gm = row0 + 32 * wave + acc_row(r, h);
-            if (gm < M) {
-                float v = acc[nt][r] + bv;
-                if (RELU) v = fmaxf(v, 0.f);
-                C[gm * ldc + n] = v;
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gm = tile * 32 + acc_row(r, h);
+                if (gm < M) {
+                    float v = acc[nt][r] + bv[nt];
+                    if (RELU) v = fmaxf(v, 0.f);
+                    C[gm * ldc + n] = v;
+                }
             }
         }
     }
 }
 
 template <int NT>
-static void launch_lds(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+static void launch_rsp(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                        int64_t M, int K, bool relu, hipStream_t s) {
-    const unsigned blocks = (unsigned)((M + 127) / 128);
-    if (relu) hipLaunchKernelGGL((linear_lds_kernel<NT, true>), dim3(blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
-    else hipLaunchKernelGGL((linear_lds_kernel<NT, false>), dim3(blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
+    const int64_t tiles = (M + 31) / 32;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 512) blocks = 512;                         // two 4-wave workgroups per CU, each wave loops over its tiles
+    if (relu) hipLaunchKernelGGL((linear_rsp_kernel<NT, true>), dim3((unsigned)blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
+    else hipLaunchKernelGGL((linear_rsp_kernel<NT, false>), dim3((unsigned)blocks), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
 }
 
 template <int NT, int KS>
@@ -333,18 +383,12 @@ template <int NT>
 static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                          int64_t M, int K, bool relu, hipStream_t s) {
     const int64_t tiles = (M + 31) / 32;
-#ifndef NCF_LINEAR_LDS
-#define NCF_LINEAR_LDS 1
-#endif
-    // A staged through LDS in full lines: measured against the global-fragment kernel (tools/ab_linear.py, M = 65 536)
-    // K = 256 -> N = 128: 64.6 vs 88.3 us, K = 64 -> N = 128: 26.2 vs 55.1 us (the shapes where that kernel splits K);
-    // slower elsewhere (K = 128: 91 vs 83 us; 1.1 M x 128 x 128: 654 vs 595 us — both kernels are bound by the
-    // fragment-shaped W loads, 32 rows x 32 B per instruction, not by A), so it is used for those two shape classes only.
-    const char* force = getenv("NCF_LINEAR_KERNEL");      // "rs" / "lds": A/B and tests; unset: by shape
-    const bool lds_ok = K % 8 == 0 && lda % 4 == 0 && aligned16(A);
-    const bool lds_wins = M >= 16384 && M <= 262144 && ((K >= 256 && NT <= 4) || K <= 64);
-    if (lds_ok && (force ? !strcmp(force, "lds") : (NCF_LINEAR_LDS && lds_wins)))
-        return launch_lds<NT>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
+    const char* force = getenv("NCF_LINEAR_KERNEL");      // "rs" / "rsp": A/B and tests; unset: by shape
+    // persistent row-streaming form: tall problems with K a multiple of 64 (bit-identical to the one-tile-per-wave form)
+    // (measured, tools/ab_linear.py: 1.1 M x 128 x 128 584 -> 488 us; 65 536 x 128 -> 256 83 -> 59 us; x 256 -> 128 74 -> 54 us;
+    // x 64 -> 128 48 -> 23 us, where the one-tile form splits K)
+    if (K % 64 == 0 && (force ? !strcmp(force, "rsp") : tiles >= 1024))
+        return launch_rsp<NT>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
     if constexpr (NT <= 4) {
         // Skinny and deep (the 4096 x 2094 -> 64 candidate Linear of AttentionNCF: 128 row tiles): one 32-column block
         // per workgroup so that tiles * NT workgroups share the chip — the rows of A are re-read once per column block

@@ -426,10 +426,10 @@ def test_small_batch_kernel_is_bit_identical_to_main_kernel(native, gpu, E, hidd
 
 
 @pytest.mark.parametrize("M,K,N,relu", [(20000, 256, 128, True), (16500, 64, 128, False), (300, 40, 64, True), (16384, 128, 256, False)])
-@pytest.mark.parametrize("kernel", ["rs", "lds"])
+@pytest.mark.parametrize("kernel", ["rs", "rsp"])
 def test_linear_kernels_agree_with_float64(native, gpu, monkeypatch, M, K, N, relu, kernel):
-    """Both row-streaming GEMM forms (A fragments from global memory / staged through LDS) against a float64 product,
-    incl. a ragged last row block and a shape the LDS form declines (K % 8 != 0 falls back by itself)."""
+    """Both row-streaming GEMM forms (one tile per wave / persistent with the A ring across tiles) against a float64
+    product, incl. a ragged last row block and a shape the persistent form declines (K % 64 != 0 falls back by itself)."""
     monkeypatch.setenv("NCF_LINEAR_KERNEL", kernel)
     g = torch.Generator().manual_seed(M + K)
     x = torch.randn(M, K, generator=g)
