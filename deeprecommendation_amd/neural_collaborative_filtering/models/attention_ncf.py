@@ -61,12 +61,27 @@ class SparseRatings:
 
     @staticmethod
     def from_dense(user_matrix: torch.Tensor, share_identical_rows: bool = True) -> "SparseRatings":
-        # the serving call (webapp/backend.py:78-121) passes ONE user's row repeated for every candidate: keep one CSR
-        # row and let every pair point at it (this function reads sizes back to the host anyway)
-        if share_identical_rows and user_matrix.shape[0] > 1 and bool((user_matrix == user_matrix[:1]).all()):
-            one = SparseRatings.from_dense(user_matrix[:1], share_identical_rows=False)
-            one.pair_row = torch.zeros(user_matrix.shape[0], dtype=torch.int64, device=user_matrix.device)
-            return one
+        """CSR of a dense (B, I) user matrix.  The reference's datasets repeat a user's row for each of their samples
+        (dynamic_datasets.py:24-40) and its web backend passes ONE row repeated for every candidate
+        (webapp/backend.py:78-121): with ``share_identical_rows`` rows that are exactly equal share one CSR row
+        (``pair_row`` maps pairs to rows), which is what lets the LDS-tiled attention kernel stage a rated set once
+        for all of its pairs.  Equal rows are found by a random projection (float64) and then VERIFIED element by
+        element; a batch of mostly distinct rows skips the verification and keeps one row per pair.  (This function
+        reads sizes back to the host in any case.)"""
+        B = user_matrix.shape[0]
+        if share_identical_rows and B > 1 and user_matrix.shape[1] > 0:
+            gen = torch.Generator(device=user_matrix.device).manual_seed(0x5EED)
+            proj = torch.rand(user_matrix.shape[1], dtype=torch.float64, device=user_matrix.device, generator=gen) + 0.5
+            key = user_matrix.double() @ proj
+            uniq, inv = torch.unique(key, return_inverse=True)
+            R = int(uniq.numel())
+            if R * SparseRatings.GROUPED_MIN_PAIRS_PER_ROW <= B:
+                rep = torch.full((R,), B, dtype=torch.int64, device=user_matrix.device)
+                rep.scatter_reduce_(0, inv, torch.arange(B, device=user_matrix.device), reduce="amin")   # first pair of each row
+                if bool((user_matrix == user_matrix[rep][inv]).all()):
+                    shared = SparseRatings.from_dense(user_matrix[rep], share_identical_rows=False)
+                    shared.pair_row = inv.contiguous()
+                    return shared
         mask = user_matrix != 0  # attention_ncf.py:158 — an entry that is exactly 0 counts as unrated
         rowptr = torch.zeros(user_matrix.shape[0] + 1, dtype=torch.int64, device=user_matrix.device)
         rowptr[1:] = torch.cumsum(mask.sum(dim=1), 0)

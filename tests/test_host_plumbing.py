@@ -182,3 +182,25 @@ def test_segmented_csr_tree_structure_cpu():
         assert bool((edge_ids[1:] > edge_ids[:-1]).all())            # partials are consumed in index (= edge) order
         prev_nseg = torch.bincount(row_of.long(), minlength=len(counts))
     assert int(prev_nseg.max()) == 1
+
+
+def test_from_dense_shares_exactly_equal_rows():
+    """SparseRatings.from_dense: repeated rows (the reference's datasets repeat a user's row per sample) share one CSR
+    row after an element-by-element verification; to_dense / expanded() give the original matrix back; a batch of
+    distinct rows keeps one row per pair."""
+    g = torch.Generator().manual_seed(0)
+    rows = torch.zeros(5, 40)
+    mask = torch.rand(5, 40, generator=g) < 0.3
+    rows[mask] = (torch.randint(1, 11, (5, 40), generator=g).float() * 0.5 - 2.9)[mask]
+    rows[3] = 0.0                                            # a user without ratings
+    pair_row = torch.randint(0, 5, (64,), generator=g)
+    um = rows[pair_row]
+    sr = SparseRatings.from_dense(um)
+    assert sr.pair_row is not None and sr.rowptr.numel() - 1 == int(torch.unique(pair_row).numel())
+    assert torch.equal(sr.to_dense(sr.val), um)
+    ex = sr.expanded()
+    assert ex.pair_row is None and torch.equal(ex.to_dense(ex.val), um)
+    plain = SparseRatings.from_dense(um, share_identical_rows=False)
+    assert torch.equal(ex.rowptr, plain.rowptr) and torch.equal(ex.col, plain.col) and torch.equal(ex.val, plain.val)
+    distinct = SparseRatings.from_dense(torch.rand(16, 40, generator=g))
+    assert distinct.pair_row is None
