@@ -15,7 +15,6 @@
 // (8 TB/s -> 15 G pairs/s): roughly balanced.
 #include "ncf_common.h"
 #include <stdlib.h>
-#include <type_traits>
 #include <string.h>
 
 #ifndef NCF_BF16_X_DEPTH
@@ -340,9 +339,6 @@ __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(
 #ifndef NCF_BF16_WS
 #define NCF_BF16_WS 1
 #endif
-#ifndef NCF_WS_REGSTAGE
-#define NCF_WS_REGSTAGE 0    // 1: gathered rows go global -> registers -> ds_write instead of LDS-DMA (A/B: tools/ab_bf16.py)
-#endif
 #ifndef NCF_BF16_WS_MIN_PAIRS
 #define NCF_BF16_WS_MIN_PAIRS 131072
 #endif
@@ -496,15 +492,9 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
         }
     };
     // one 1-KiB piece (8 pairs x 128 B) of a tile's X image: column tile ct, 128-byte unit cu, pair group w
-    auto piece_ptr = [&](const RowSrc& src, int ct, int cu) {
-        const bool fromA = cu < ncuA;
-        return (fromA ? src[ct][0] : src[ct][1]) + (fromA ? cu : cu - ncuA) * 128;
-    };
-    auto piece_lds = [&](int buf, int ct, int cu) { return buf * L::XBUF + ct * L::CT_BYTES + (cu * 4 + w) * 1024; };
-    // register staging (NCF_WS_REGSTAGE): tile T's pieces wait in stg[T & 1] between their load and their ds_write
-    u32x4 stg[NCF_WS_REGSTAGE ? 2 : 1][NCF_WS_REGSTAGE ? CTN * NCU : 1];
     auto issue_piece = [&](const RowSrc& src, int buf, int ct, int cu) {
-        const unsigned char* gp = piece_ptr(src, ct, cu);
+        const bool fromA = cu < ncuA;
+        const unsigned char* gp = (fromA ? src[ct][0] : src[ct][1]) + (fromA ? cu : cu - ncuA) * 128;
         if (NCF_BF16_ABLATE == 1 || NCF_BF16_ABLATE == 5) return;  // diagnostics: no row DMAs
         if (NCF_BF16_ABLATE == 3) gp = reinterpret_cast<const unsigned char*>(a.tabA) + ((gp - reinterpret_cast<const unsigned char*>(a.tabA)) & 0xFFFFF);  // diagnostics: rows from a 1 MiB window
         dma16(gp, lds0 + buf * L::XBUF + ct * L::CT_BYTES + (cu * 4 + w) * 1024);
@@ -524,30 +514,15 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
         }
         __builtin_amdgcn_sched_barrier(0);
         if (e3) ids_dma(tile + 3 * stride, 1);
-        if (NCF_WS_REGSTAGE) {
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct)
+#pragma unroll
+            for (int cu = 0; cu < NCU; ++cu) issue_piece(src0, 0, ct, cu);
+        if (e1) {
 #pragma unroll
             for (int ct = 0; ct < CTN; ++ct)
 #pragma unroll
-                for (int cu = 0; cu < NCU; ++cu) {
-                    stg[0][ct * NCU + cu] = ldg16(piece_ptr(src0, ct, cu));
-                    stg[NCF_WS_REGSTAGE ? 1 : 0][ct * NCU + cu] = ldg16(e1 ? piece_ptr(src1, ct, cu) : zeros);
-                }
-#pragma unroll
-            for (int ct = 0; ct < CTN; ++ct)
-#pragma unroll
-                for (int cu = 0; cu < NCU; ++cu)
-                    *reinterpret_cast<u32x4*>(lds + piece_lds(0, ct, cu) + lane * 16) = stg[0][ct * NCU + cu];
-        } else {
-#pragma unroll
-            for (int ct = 0; ct < CTN; ++ct)
-#pragma unroll
-                for (int cu = 0; cu < NCU; ++cu) issue_piece(src0, 0, ct, cu);
-            if (e1) {
-#pragma unroll
-                for (int ct = 0; ct < CTN; ++ct)
-#pragma unroll
-                    for (int cu = 0; cu < NCU; ++cu) issue_piece(src1, 1, ct, cu);
-            }
+                for (int cu = 0; cu < NCU; ++cu) issue_piece(src1, 1, ct, cu);
         }
     }
     // the weights are older than every DMA: using them here lets hipcc retire its own waits for them now instead of
@@ -558,10 +533,8 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
 #pragma unroll
         for (int s = 0; s < Q2; ++s) asm volatile("" ::"v"(wa2[s]));
     }
-    if (!NCF_WS_REGSTAGE) {
-        if (e1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (e1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -631,10 +604,7 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
     for (int nt = 0; nt < 2; ++nt) acc1[nt][0] = bias_tile(L::OFF_B1, 64 * w + 32 * nt);
     const unsigned char* hbase = lds + L::OFF_H1 + lane * 16;
 
-    int it = 0;
-    auto body = [&](auto parity_c) {
-        constexpr int PAR = decltype(parity_c)::value;       // it & 1 at compile time: selects the staging register set
-        (void)PAR;
+    for (int it = 0; tile < ntiles; ++it, tile += stride) {
         const int buf = it % 3, nbuf = (it + 1) % 3;
         WS_STAMP(0);
 #if NCF_BF16_STAMP
@@ -658,8 +628,7 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
             if (ct == 0) {
                 // phase A fillers: one row-DMA piece per k-step, then the previous tile's ct1 dot in quarters
                 if (s < ROWS) {
-                    if (NCF_WS_REGSTAGE) stg[NCF_WS_REGSTAGE ? PAR : 0][s] = ldg16(has2 ? piece_ptr(src, s / NCU, s % NCU) : zeros);
-                    else if (has2) issue_piece(src, (it + 2) % 3, s / NCU, s % NCU);
+                    if (has2) issue_piece(src, (it + 2) % 3, s / NCU, s % NCU);
                 } else if (it > 0 && NCF_BF16_ABLATE != 5) {
                     constexpr int DQ = 4 * NPREV;            // dot quarters to place
                     const int k = s - ROWS;
@@ -739,18 +708,10 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
                     }
                     if (q == BODY2 - 1) {
                         if (ct == 0) {
-                            if (NCF_WS_REGSTAGE) {
-                                // rows(it+1), loaded during the previous iteration's phase A, go to their X buffer now; the
-                                // compiler's own wait for them also covers ids(it+3), which is older in the queue
-#pragma unroll
-                                for (int pc_ = 0; pc_ < ROWS; ++pc_)
-                                    *reinterpret_cast<u32x4*>(lds + piece_lds(nbuf, pc_ / NCU, pc_ % NCU) + lane * 16) = stg[NCF_WS_REGSTAGE ? (PAR ^ 1) : 0][pc_];
-                            } else {
-                                // this wave's pieces of rows(it+1) (and ids(it+3)) have landed once only this iteration's DMAs are left
-                                if (has4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS + 1) : "memory");
-                                else if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS) : "memory");
-                                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            }
+                            // this wave's pieces of rows(it+1) (and ids(it+3)) have landed once only this iteration's DMAs are left
+                            if (has4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS + 1) : "memory");
+                            else if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                             __builtin_amdgcn_s_barrier();    // beta: H1(ct1) and rows(it+1) are visible
                             WS_STAMP(4);
@@ -774,15 +735,9 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                    // alpha: the previous tile's dots are visible
             if (it > 0) store_out(tile - stride);
-            if (NCF_WS_REGSTAGE) {
-#pragma unroll
-                for (int pc_ = 0; pc_ < ROWS; ++pc_)
-                    *reinterpret_cast<u32x4*>(lds + piece_lds(nbuf, pc_ / NCU, pc_ % NCU) + lane * 16) = stg[NCF_WS_REGSTAGE ? (PAR ^ 1) : 0][pc_];
-            } else {
-                if (has4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS + 1) : "memory");
-                else if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (has4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS + 1) : "memory");
+            else if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (has3) locate_lds(src, tile + 3 * stride, (it + 1) & 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                    // beta: rows(it+1) are visible; wave 0 is done with the dots
@@ -802,17 +757,6 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
             if constexpr (N2 > 0) asm volatile("" ::"a"(acc2[0]), "a"(acc2[1]));
         }
         WS_STAMP(6);
-    };
-    while (tile < ntiles) {
-        body(std::integral_constant<int, 0>{});
-        ++it;
-        tile += stride;
-        if (NCF_WS_REGSTAGE) {
-            if (tile >= ntiles) break;
-            body(std::integral_constant<int, 1>{});
-            ++it;
-            tile += stride;
-        }
     }
     if (oob_seen && a.oob) *a.oob = 1;
     // the last tile's deferred dot and output
