@@ -111,3 +111,51 @@ def test_spmm_random_graphs(N, D4, E, seg, seed):
     mag = torch.zeros(N, D, dtype=torch.float64).index_add_(0, dst, coef.double().abs()[:, None] * z.double()[col].abs())
     tol = 2e-6 * mag + 2e-5 * float(ref.abs().max()) + 1e-6
     assert bool(((y.cpu().double() - ref).abs() <= tol).all())
+
+
+def test_status_codes_of_the_round1_late_entries(native, gpu):
+    """Argument checking of the entries added for grouped attention and the training step."""
+    lib = native.load_library()
+    f = torch.zeros(64, 64, device=gpu)
+    i64 = torch.zeros(8, dtype=torch.long, device=gpu)
+    i32 = torch.zeros(8, dtype=torch.int32, device=gpu)
+    # grouped attention: linear mode has no LDS-tiled form; A must be a multiple of 4; pairs_per_wg in 1..32
+    args = lambda mode, A, ppw: lib.ncf_attn_forward_grouped(mode, f.data_ptr(), 64, f.data_ptr(), 64, A, f.data_ptr(), 0.0, i64.data_ptr(),
+                                                             i32.data_ptr(), f.data_ptr(), 1, 64, i64.data_ptr(), i64.data_ptr(), i64.data_ptr(),
+                                                             4, ppw, f.data_ptr(), 64, 64, None, f.data_ptr(), 64, None, None, None)
+    assert args(native.ATT_LINEAR, 1, 8) == native.NCF_EUNSUPPORTED
+    assert args(native.ATT_MLP, 6, 8) == native.NCF_EUNSUPPORTED
+    assert args(native.ATT_MLP, 64, 0) == native.NCF_EINVAL
+    assert args(native.ATT_MLP, 64, 33) == native.NCF_EINVAL
+    assert not native.attn_grouped_supported(native.ATT_LINEAR, 1, 64) and native.attn_grouped_supported(native.ATT_COS, 64, 256)
+    # weights requested without their offsets
+    assert lib.ncf_attn_forward_grouped(native.ATT_MLP, f.data_ptr(), 64, f.data_ptr(), 64, 64, f.data_ptr(), 0.0, i64.data_ptr(), i32.data_ptr(),
+                                        f.data_ptr(), 1, 64, i64.data_ptr(), i64.data_ptr(), i64.data_ptr(), 4, 8, f.data_ptr(), 64, 64, None,
+                                        f.data_ptr(), 64, f.data_ptr(), None, None) == native.NCF_EINVAL
+    # grouping: workspace too small
+    need = lib.ncf_group_pairs_workspace_bytes(100)
+    assert need >= 2 * 100 * 4
+    ws = torch.zeros(need, dtype=torch.uint8, device=gpu)
+    assert lib.ncf_group_pairs(i64.data_ptr(), 8, 100, 8, i64.data_ptr(), i64.data_ptr(), i64.data_ptr(), ws.data_ptr(), need - 1, None, None) == native.NCF_EWORKSPACE
+    # an out-of-range pair_row raises at the next check (sticky flag), the pair is dropped
+    bad = torch.tensor([0, 1, 7, 1], dtype=torch.long, device=gpu)
+    grp_ptr, pair_ids, wg_ptr = native.group_pairs(bad, 2, 8)
+    assert int(grp_ptr[-1]) == 3
+    with pytest.raises(IndexError):
+        native.check_oob(gpu)
+    # Adam: step counts from 1, tensors must be 16-byte aligned
+    assert lib.ncf_adam_step(f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None) == native.NCF_EINVAL
+    assert lib.ncf_adam_step(f.data_ptr() + 4, f.data_ptr(), f.data_ptr(), f.data_ptr(), 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) == native.NCF_EINVAL
+    # column gather: leading dimension smaller than the number of columns
+    assert lib.ncf_gather_cols(f.data_ptr(), 32, None, i64.data_ptr(), 8, 64, 64, f.data_ptr(), 64, None, None) == native.NCF_EINVAL
+    assert lib.ncf_scatter_add_cols(f.data_ptr(), 64, i64.data_ptr(), 8, 64, f.data_ptr(), 32, 64, None, None) == native.NCF_EINVAL
+    # and both column kernels against torch on a contiguous [E, U] weight (the id-major layout takes the row kernels)
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(16, 50, generator=g).to(gpu)
+    b = torch.randn(16, generator=g).to(gpu)
+    idx = torch.randint(0, 50, (200,), generator=g).to(gpu)
+    assert torch.equal(native.gather_cols(W, b, idx), W.t()[idx] + b)
+    src = torch.randn(200, 16, generator=g).to(gpu)
+    dst = native.scatter_add_cols(src, idx, torch.zeros(16, 50, device=gpu))
+    ref = torch.zeros(50, 16, device=gpu).index_add_(0, idx, src).t()
+    assert float((dst - ref).abs().max()) <= 1e-5
