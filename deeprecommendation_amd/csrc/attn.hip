@@ -245,8 +245,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ pc,
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // FO = output registers per lane = ceil(Fdim / 64); NPF = 16-byte pieces of a tile each thread stages = (A + Fdim) / 32 rounded up to 4 / 8 / 16
+#ifndef ATT_G_WAVES_PER_SIMD
+#define ATT_G_WAVES_PER_SIMD 2   // one 512-thread workgroup per CU at 198 VGPRs; 4 (two workgroups, 128 VGPRs) spills 74+ registers
+#endif
 template <int MODE, int FO, int NPF>
-__global__ __launch_bounds__(512) void attn_grouped_kernel(const float* __restrict__ pc, int64_t ldpc, const float* __restrict__ pr,
+__global__ __launch_bounds__(512, ATT_G_WAVES_PER_SIMD) void attn_grouped_kernel(const float* __restrict__ pc, int64_t ldpc, const float* __restrict__ pr,
                                                            int64_t ldpr, int A, const float* __restrict__ w1, float b1,
                                                            const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const float* __restrict__ val, int64_t R, int64_t I,
