@@ -34,7 +34,9 @@ class SparseRatings:
     ``pair_row[b]`` — the dense matrix repeats a user's row for each of their pairs (dynamic_datasets.py:24-40); sharing
     it is what lets the LDS-tiled attention kernel stage a user's rated rows once for all of their pairs."""
 
-    GROUPED_MIN_PAIRS_PER_ROW = 4   # below this the per-pair kernel is used (nothing to share)
+    # below this average the per-pair kernel is used.  Measured at config-3 shapes (tools/ab_attn_grouped.py threshold),
+    # grouped vs per-pair: 1 pair per set 335 vs 154 us, 2: 216 vs 153, 4: 128 vs 152, 8: 77 vs 151, 16+: 57 vs 147
+    GROUPED_MIN_PAIRS_PER_ROW = 4
 
     def __init__(self, rowptr, col, val, num_items, pair_row=None):
         self.rowptr, self.col, self.val, self.num_items = rowptr, col, val, int(num_items)

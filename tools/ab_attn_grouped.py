@@ -46,6 +46,11 @@ def case(B=4096, users=64, nnz=256, A=128, F=64, I=100_000):
     print("  ".join(res), flush=True)
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "threshold":
+    # pairs per rated set at which the grouped kernel overtakes the per-pair kernel (SparseRatings.GROUPED_MIN_PAIRS_PER_ROW)
+    for users in (4096, 2048, 1024, 512, 256, 128):
+        case(users=users)
+    sys.exit(0)
 case()
 case(nnz=64)
 case(A=64)
