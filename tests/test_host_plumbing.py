@@ -126,6 +126,16 @@ def test_dataset_collate_and_model_contract(tmp_path):
     m.save_model(tmp_path / "m.pt")
     m2 = load_model(tmp_path / "m.pt", BasicNCF)
     assert m2.kwargs == m.kwargs and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    # embedding weights are stored id-major (transpose views) but keep the nn.Linear shape and state_dict entry: a plain
+    # contiguous nn.Linear — what the reference's BasicNCF holds — loads the saved tensor as is
+    w = m.user_embeddings[0].weight
+    assert tuple(w.shape) == (8, 3) and not w.is_contiguous() and w.t().is_contiguous()
+    saved, _ = torch.load(tmp_path / "m.pt", weights_only=True)
+    ref_like = torch.nn.Linear(3, 8)
+    ref_like.load_state_dict({"weight": saved["user_embeddings.0.weight"], "bias": saved["user_embeddings.0.bias"]})
+    assert ref_like.weight.is_contiguous() and torch.equal(ref_like.weight, w)
+    x = torch.eye(3)
+    assert torch.equal(ref_like(x), m.user_embeddings(x))
     # training step stays on differentiable torch ops and works on CPU
     m.train()
     out = m(u, i)
