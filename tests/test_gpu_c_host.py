@@ -1,7 +1,6 @@
 """The C ABI is usable without Python or torch: a C++ host program (tests/c_host/abi_host.cpp) that includes only
 include/ncf_abi.h and the HIP runtime is compiled with hipcc against the in-tree libncf_hip.so and run on the GPU."""
 import os
-import shutil
 import subprocess
 
 import pytest
