@@ -25,9 +25,11 @@ def build_variant(i, flags):
 def main():
     variants = sys.argv[1:] or [""]
     dev = torch.device("cuda:0")
-    U, I, E, Bsz = 4_000_000, 1_000_000, 128, int(os.environ.get("AB_B", 65536))
+    U, I, E, Bsz = int(os.environ.get("AB_U", 4_000_000)), int(os.environ.get("AB_I", 1_000_000)), 128, int(os.environ.get("AB_B", 65536))
     g = torch.Generator(device=dev).manual_seed(1)
-    tu = (torch.randn(U, E, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+    tu = torch.empty(U, E, dtype=torch.bfloat16, device=dev)
+    for s0 in range(0, U, 4_000_000):   # chunked: a 100 M-row table is 25.6 GB in bf16, its fp32 source would be twice that
+        tu[s0:s0 + 4_000_000] = (torch.randn(min(4_000_000, U - s0), E, device=dev, generator=g) * 0.05).to(torch.bfloat16)
     ti = (torch.randn(I, E, device=dev, generator=g) * 0.05).to(torch.bfloat16)
     dims = [256, 256, 128, 1]
     ws = [torch.randn(dims[i + 1], dims[i], device=dev, generator=g) / dims[i] ** 0.5 for i in range(3)]
