@@ -275,6 +275,9 @@ __global__ __launch_bounds__(256) void linear_rs_kernel(const float* __restrict_
 // set-up and a cold first fetch (~2 us exposed against ~8 us of MFMAs, measured 571 us on 1.1 M x 128 x 128 where the
 // MFMAs alone are 229 us and HBM 225 us); neither deeper prefetch inside a tile (571 vs 586 us), nor staging A or A and W
 // through LDS (654 / 702 us) moved it — see tools/ab_linear.py.  Same k order per output: bit-identical results.
+#ifndef NCF_RSP_ABLATE
+#define NCF_RSP_ABLATE 0   // diagnostics (tools/ab_linear_variants.py): 1 = no C stores, 2 = W fragments loaded once per tile, 3 = both
+#endif
 template <int NT, bool RELU>
 __global__ __launch_bounds__(256) void linear_rsp_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                          int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
@@ -322,7 +325,9 @@ __global__ __launch_bounds__(256) void linear_rsp_kernel(const float* __restrict
             for (int d = 0; d < PD; d += 2) {
                 const int q = qb + d;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) w1[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt] + 8 * (q + 1));   // q + 1 < Q: Q is even
+                for (int nt = 0; nt < NT; ++nt)
+                    if (!(NCF_RSP_ABLATE & 2)) w1[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt] + 8 * (q + 1));   // q + 1 < Q: Q is even
+                    else w1[nt] = w0[nt];
                 {
                     const f32x4 a = ar[d];
                     ar[d] = a_at(p0 + q + PD);
@@ -332,7 +337,8 @@ __global__ __launch_bounds__(256) void linear_rsp_kernel(const float* __restrict
                         for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w0[nt][j], acc[nt], 0, 0, 0);
                 }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) w0[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt] + 8 * (q + 2 < Q ? q + 2 : 0));
+                for (int nt = 0; nt < NT; ++nt)
+                    if (!(NCF_RSP_ABLATE & 2)) w0[nt] = *reinterpret_cast<const f32x4u*>(wrow[nt] + 8 * (q + 2 < Q ? q + 2 : 0));
                 {
                     const f32x4 a = ar[d + 1];
                     ar[d + 1] = a_at(p0 + q + 1 + PD);
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(256) void linear_rsp_kernel(const float* __restrict
                 if (gm < M) {
                     float v = acc[nt][r] + bv[nt];
                     if (RELU) v = fmaxf(v, 0.f);
-                    C[gm * ldc + n] = v;
+                    if (!(NCF_RSP_ABLATE & 1) || v == 12345.678f) C[gm * ldc + n] = v;
                 }
             }
         }
