@@ -245,6 +245,54 @@ def test_full_size_cfg2_properties(native, gpu):
     native.check_oob(gpu)
 
 
+def test_full_size_cfg5_properties(native, gpu, monkeypatch):
+    """BASELINE configs[4] at one GPU's full size (100 M x 128 and 10 M x 128 bf16 tables = 28 GB, MLP 256-256-128-1):
+    size-independent properties of BOTH bf16 kernels at 65 536 and 262 144 pairs — (a) permuting the batch permutes the
+    output bit-exactly, (b) extreme row ids (0, last) are read correctly, (c) the two kernels agree within the bf16
+    tolerance, (d) a subsample agrees with a float64 evaluation of the same bf16-rounded operands."""
+    free, _ = torch.cuda.mem_get_info(gpu)
+    if free < 40 << 30:
+        pytest.skip("needs 40 GB of free HBM")
+    U, I, E = 100_000_000, 10_000_000, 128
+    g = torch.Generator(device=gpu).manual_seed(5)
+
+    def table(rows):
+        t = torch.empty((rows, E), dtype=torch.bfloat16, device=gpu)
+        for s0 in range(0, rows, 5_000_000):
+            t[s0:s0 + 5_000_000] = (torch.randn((min(5_000_000, rows - s0), E), device=gpu, generator=g) * 0.05).to(torch.bfloat16)
+        return t
+
+    tu, ti = table(U), table(I)
+    dims = [2 * E, 256, 128, 1]
+    ws = [torch.randn(dims[k + 1], dims[k], device=gpu, generator=g) / dims[k] ** 0.5 for k in range(3)]
+    bs = [torch.randn(dims[k + 1], device=gpu, generator=g) * 0.1 for k in range(3)]
+    packed = native.PackedMLP(ws, bs, dtype=torch.bfloat16)
+    wr = [w.to(torch.bfloat16).double().cpu() for w in ws[:2]] + [ws[2].double().cpu()]
+    for B in (65536, 262144):
+        iu = torch.randint(0, U, (B,), device=gpu, generator=g)
+        ii = torch.randint(0, I, (B,), device=gpu, generator=g)
+        iu[0], iu[1], ii[0], ii[1] = 0, U - 1, I - 1, 0
+        perm = torch.randperm(B, device=gpu, generator=g)
+        outs = {}
+        for kernel in ("stream", "ws"):
+            monkeypatch.setenv("NCF_BF16_KERNEL", kernel)
+            out = native.score_fused(tu, iu, ti, ii, packed)
+            outp = native.score_fused(tu, iu[perm].contiguous(), ti, ii[perm].contiguous(), packed)
+            assert torch.equal(outp, out[perm]), kernel
+            outs[kernel] = out
+        assert_close(outs["ws"], outs["stream"].cpu(), rtol=2e-3)
+        sub = torch.cat((torch.arange(0, 4, device=gpu), torch.arange(4, B, 1021, device=gpu)))
+        x = torch.cat((tu[iu[sub]], ti[ii[sub]]), 1).double().cpu()
+        h = torch.relu(x @ wr[0].t() + bs[0].double().cpu()).float().to(torch.bfloat16).double()
+        h = torch.relu(h @ wr[1].t() + bs[1].double().cpu())
+        ref = (h @ wr[2].t() + bs[2].double().cpu()).float()
+        for kernel in ("stream", "ws"):
+            assert_close(outs[kernel][sub], ref, rtol=2e-3)
+    native.check_oob(gpu)
+    del tu, ti
+    torch.cuda.empty_cache()
+
+
 # ----------------------------------------------------------------------------- bf16 fused path (BASELINE config 5 arithmetic)
 @pytest.mark.parametrize("E,hidden", [(128, [256, 128]), (128, [256]), (64, [256, 128]), (64, [256])])
 @pytest.mark.parametrize("B", [1, 63, 255, 256, 257, 3000, 40000, 100001, 140000])
