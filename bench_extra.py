@@ -193,6 +193,7 @@ def run_cfg3(args, device):
                                    "catalogue projections precomputed; attention net split + UserEmbeddings linearity; "
                                    + ("step = batch copied into static buffers + ONE HIP-graph launch" if wall_graph is not None and wall == wall_graph and wall_graph < wall_eager
                                       else "step enqueued kernel by kernel from Python"),
+                       "reference_formulation_mfma_bound_pairs_per_s": 157.3e12 / (nnz * (2 * 2 * IE * A + 2 * A) + 2 * (128 * 256 + 256 * 128 + 128)),
                        "eager_ms_per_step": wall_eager / args.steps * 1e3, "eager_pairs_per_s": B * args.steps / wall_eager,
                        "graph_replay_ms_per_step": None if graph_err or os.environ.get("NCF_CFG3_NO_GRAPH") == "1" else wall_graph / args.steps * 1e3,
                        "graph_error": graph_err},
