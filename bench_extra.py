@@ -34,6 +34,20 @@ def _time_steps(step, warmup, steps):
     return time.perf_counter() - t0, e0.elapsed_time(e1) * 1e-3
 
 
+def _cpu_median_s(fn, reps, warm=2):
+    """Median wall time of fn() on the host cores (torch CPU threads = the process's CPU share)."""
+    import bench
+    torch.set_num_threads(bench.host_cores())
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2], bench.host_cores()
+
+
 def _per_launch_us(fn, reps=50):
     for _ in range(3):
         fn()
@@ -104,6 +118,22 @@ def run_cfg4(args, device):
             "roofline": {"kernel": f"spmm_seg_kernel<32> x{len(prep.csr.levels)} levels (edge pass + ordered partial tree)", "bound": "hbm", "achieved": gbs, "peak": 8000.0,
                          "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None, "us_per_launch": us,
                          "algorithmic_bytes_per_edge": bytes_per_edge, "hoisted_gemm_us": gemm_us}}
+    if not getattr(args, "no_cpu_baseline", False):
+        # CPU oracle, reference formulation (per-EDGE Linear + scatter-add, gnn_ncf.py:39-94) on a graph 100x smaller:
+        # 10 000 users x 1 000 items, 500 000 interactions (the full graph's per-edge messages alone are 51 GB)
+        from oracle import ncf_oracle as O
+        gc = torch.Generator().manual_seed(11)
+        Ic, Uc, nc = 1_000, 10_000, 500_000
+        pc_ = 1.0 / torch.arange(1, Ic + 1, dtype=torch.float64)
+        it = torch.multinomial((pc_ / pc_.sum()).float(), nc, replacement=True, generator=gc)
+        us_ = torch.randint(0, Uc, (nc,), generator=gc) + Ic
+        at = torch.randint(1, 11, (nc,), generator=gc).float() * 0.5 - 3.0
+        xc = torch.randn(Ic + Uc, D, generator=gc) * 0.05
+        cs = {k: v.detach().cpu() for k, v in model.gnn_convs[0].state_dict().items()}
+        sec, cores = _cpu_median_s(lambda: O.lightgcn_conv(xc, cs, True, torch.stack([us_, it]), torch.stack([it, us_]), at, at), reps=5)
+        line["cpu_baseline"] = {"value": 2 * nc / sec, "unit": "edges/s", "cores": cores, "kind": "port",
+                                "sample": f"reference formulation (per-edge Linear + index_add) of ONE layer on {Uc} users x {Ic} items, "
+                                          f"{2 * nc} directed edges, D={D}, median of 5 ({sec * 1e3:.0f} ms each), torch CPU fp32"}
     print(json.dumps(line), flush=True)
 
 
@@ -207,6 +237,26 @@ def run_cfg3(args, device):
                          "note": "the grouped kernel is VALU / LDS bound (its tiles come from L2 / the Infinity Cache once per "
                                  "workgroup): the byte rate is what it needs, not what limits it; the per-pair kernel's tables "
                                  "(51 MB + 26 MB) are cache resident: gathered cache bandwidth, HBM peak is the reference line"}}
+    if not getattr(args, "no_cpu_baseline", False):
+        # CPU oracle, reference formulation (materialised candidate x rated pairs, attention_ncf.py:154-213) on a down-scaled
+        # sample: 64 pairs of 16 users against those users' own rated items (the full 4096 x 100k pair grid is 2·B·I·IE floats)
+        from oracle import ncf_oracle as O
+        state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        gcpu = torch.Generator().manual_seed(3)
+        users = 16
+        colc = torch.stack([torch.randperm(I, generator=gcpu)[:nnz].sort().values for _ in range(users)])
+        rated_ids = torch.unique(colc)
+        rated_cpu = catalogue[rated_ids.to(device)].cpu()
+        who_c = torch.randint(0, users, (64,), generator=gcpu)
+        um = torch.zeros(64, rated_ids.numel())
+        pos = torch.searchsorted(rated_ids, colc)
+        for b_ in range(64):
+            um[b_, pos[who_c[b_]]] = torch.randint(1, 11, (nnz,), generator=gcpu).float() * 0.5 - 2.9
+        cand_cpu = catalogue[torch.randint(0, I, (64,), generator=gcpu).to(device)].cpu()
+        sec, cores = _cpu_median_s(lambda: O.attention_ncf_forward(state, cand_cpu, rated_cpu, um), reps=5)
+        line["cpu_baseline"] = {"value": 64 / sec, "unit": "pairs/s", "cores": cores, "kind": "port",
+                                "sample": f"reference formulation on 64 pairs of {users} users x {nnz} rated against their {int(rated_ids.numel())} rated items, "
+                                          f"median of 5 forwards ({sec * 1e3:.0f} ms each), torch CPU fp32"}
     print(json.dumps(line), flush=True)
 
 
