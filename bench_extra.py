@@ -271,6 +271,9 @@ def run_cfg5(args, device):
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
     U, I, E, B = 100_000_000, 10_000_000, 128, 65_536
+    strong = os.environ.get("NCF_CFG5_STRONG") == "1"   # fixed global batch of 65 536 pairs (SURVEY 8d cfg 5, second form)
+    if strong:
+        B = B // world
     replicate = os.environ.get("NCF_REPLICATE_ITEMS", "1") == "1"
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     ulo, uhi = RowShardedTable.shard_bounds(U, world, rank)
@@ -332,7 +335,7 @@ def run_cfg5(args, device):
     if rank == 0:
         line = {"metric": "scored user-item pairs/sec", "value": world * B * args.steps / wall, "unit": "pairs/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"cfg5: BasicNCF {U} users x {I} items, emb_dim={E} bf16, local batch {B}, MLP 256-256-128-1, "
                                        f"user table row-sharded x{world}, item table {'replicated' if replicate else 'row-sharded'}, "
                                        "unique-id dedup before the all-to-all",
