@@ -130,10 +130,10 @@ def run_cfg4(args, device):
         at = torch.randint(1, 11, (nc,), generator=gc).float() * 0.5 - 3.0
         xc = torch.randn(Ic + Uc, D, generator=gc) * 0.05
         cs = {k: v.detach().cpu() for k, v in model.gnn_convs[0].state_dict().items()}
-        sec, cores = _cpu_median_s(lambda: O.lightgcn_conv(xc, cs, True, torch.stack([us_, it]), torch.stack([it, us_]), at, at), reps=5)
+        sec, cores = _cpu_median_s(lambda: O.lightgcn_conv(xc, cs, True, torch.stack([us_, it]), torch.stack([it, us_]), at, at), reps=20, warm=5)
         line["cpu_baseline"] = {"value": 2 * nc / sec, "unit": "edges/s", "cores": cores, "kind": "port",
                                 "sample": f"reference formulation (per-edge Linear + index_add) of ONE layer on {Uc} users x {Ic} items, "
-                                          f"{2 * nc} directed edges, D={D}, median of 5 ({sec * 1e3:.0f} ms each), torch CPU fp32"}
+                                          f"{2 * nc} directed edges, D={D}, median of 20 after 5 warm-ups ({sec * 1e3:.0f} ms each), torch CPU fp32"}
     print(json.dumps(line), flush=True)
 
 
@@ -253,10 +253,10 @@ def run_cfg3(args, device):
         for b_ in range(64):
             um[b_, pos[who_c[b_]]] = torch.randint(1, 11, (nnz,), generator=gcpu).float() * 0.5 - 2.9
         cand_cpu = catalogue[torch.randint(0, I, (64,), generator=gcpu).to(device)].cpu()
-        sec, cores = _cpu_median_s(lambda: O.attention_ncf_forward(state, cand_cpu, rated_cpu, um), reps=5)
+        sec, cores = _cpu_median_s(lambda: O.attention_ncf_forward(state, cand_cpu, rated_cpu, um), reps=20, warm=5)
         line["cpu_baseline"] = {"value": 64 / sec, "unit": "pairs/s", "cores": cores, "kind": "port",
                                 "sample": f"reference formulation on 64 pairs of {users} users x {nnz} rated against their {int(rated_ids.numel())} rated items, "
-                                          f"median of 5 forwards ({sec * 1e3:.0f} ms each), torch CPU fp32"}
+                                          f"median of 20 forwards after 5 warm-ups ({sec * 1e3:.0f} ms each), torch CPU fp32"}
     print(json.dumps(line), flush=True)
 
 
