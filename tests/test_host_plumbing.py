@@ -214,3 +214,24 @@ def test_from_dense_shares_exactly_equal_rows():
     assert torch.equal(ex.rowptr, plain.rowptr) and torch.equal(ex.col, plain.col) and torch.equal(ex.val, plain.val)
     distinct = SparseRatings.from_dense(torch.rand(16, 40, generator=g))
     assert distinct.pair_row is None
+
+
+def test_gpu_only_helpers_fail_loudly_on_cpu():
+    """No CPU fallback: the HIP-side helpers added for grouped attention, graph replay and the fused optimiser raise on
+    CPU tensors / without a GPU instead of computing something else."""
+    from deeprecommendation_amd import native
+    from deeprecommendation_amd.optim import FusedAdam
+    assert native.default_pairs_per_wg(4096) == 32 and native.default_pairs_per_wg(600) == 16 and native.default_pairs_per_wg(10) == 8
+    assert native.attn_grouped_supported(native.ATT_MLP, 128, 64) and not native.attn_grouped_supported(native.ATT_MLP, 130, 64)
+    p = torch.nn.Parameter(torch.zeros(4, 4))
+    p.grad = torch.ones(4, 4)
+    with pytest.raises(RuntimeError, match="GPU"):
+        FusedAdam([p]).step()
+    with pytest.raises(ValueError):
+        FusedAdam([p], lr=-1.0)
+    if not torch.cuda.is_available():
+        from deeprecommendation_amd.graphs import GraphedForward
+        with pytest.raises(RuntimeError, match="GPU"):
+            GraphedForward(lambda x: x, [torch.zeros(2)])
+        with pytest.raises(RuntimeError):
+            native.group_pairs(torch.zeros(4, dtype=torch.int64), 2, 8)
