@@ -323,8 +323,8 @@ def run_cfg5(args, device):
     us = _per_launch_us(lambda: native.score_fused(urows, uinv, irows, iinv, model.packed, out=out), reps=100)
     flop = 2 * (256 * 256 + 256 * 128 + 128)
     tf = flop * B / (us * 1e-6) / 1e12
-    # the same arithmetic on a 16x larger local batch straight off this rank's shards (random local rows from HBM): from
-    # 131 072 pairs up the library switches to the weight-stationary persistent kernel
+    # the same kernel (weight-stationary persistent) on a 16x larger local batch straight off this rank's shards (random
+    # local rows from HBM)
     BL = 16 * B
     gl = torch.Generator(device=device).manual_seed(77 + rank)
     lu = torch.randint(0, tu.shape[0], (BL,), device=device, generator=gl)
@@ -340,7 +340,7 @@ def run_cfg5(args, device):
                                        f"user table row-sharded x{world}, item table {'replicated' if replicate else 'row-sharded'}, "
                                        "unique-id dedup before the all-to-all",
                            "exchange_stats_rank0": model.users.last_stats},
-                "roofline": {"kernel": "score_fused_bf16_kernel<256,256,128>", "bound": "mfma", "achieved": tf, "peak": 2500.0,
+                "roofline": {"kernel": "score_ws_bf16_kernel<256,256,128>", "bound": "mfma", "achieved": tf, "peak": 2500.0,
                              "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None, "us_per_launch": us,
                              "algorithmic_flop_per_pair": flop, "algorithmic_bytes_per_pair": 532,
                              "hbm_GBps_at_this_rate": 532 * B / (us * 1e-6) / 1e9},

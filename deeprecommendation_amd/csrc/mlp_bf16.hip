@@ -340,7 +340,7 @@ __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(
 #define NCF_BF16_WS 1
 #endif
 #ifndef NCF_BF16_WS_MIN_PAIRS
-#define NCF_BF16_WS_MIN_PAIRS 131072
+#define NCF_BF16_WS_MIN_PAIRS 1
 #endif
 
 #if NCF_BF16_STAMP
@@ -910,11 +910,12 @@ int bf16_score(const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, i
 #if NCF_BF16_STAMP
     a.dbg = g_bf16_dbg;
 #endif
-    // Weight-stationary persistent kernel for large batches whose row widths are whole 128-byte units, else the
-    // slab-streaming one.  Measured crossover (E = 128, 256-256-128-1): 65 536 pairs 21 us vs 19.7 us (its prologue —
-    // ids, then rows, then weights into registers — is 6 us for 4 tiles per workgroup); 262 144 pairs and up 19-28 %
-    // faster.  NCF_BF16_KERNEL=ws|stream in the environment overrides the choice (tests use it to run the edge-case
-    // batches through both).
+    // Weight-stationary persistent kernel whenever the row widths are whole 128-byte units and ids are given, else the
+    // slab-streaming one.  Measured (tools/ab_bf16.py, E = 128, 256-256-128-1, interleaved in one process), ws vs streaming:
+    // 512..8192 pairs 7.6-8.0 vs 13.6-14.6 us; 16 384: 8.7 vs 15.0; 32 768: 13.3 vs 16.8; 49 152: 16.6 vs 18.4; 65 536: 20.3 vs
+    // 19.9 (4 M-row tables) and 20.9 vs 23.0 (100 M-row tables, config 5); 73 728: 21.9 vs 34.2 (the streaming kernel's
+    // 256-pair workgroups go to a second round past one per CU); 131 072: 33.8 vs 38.9; 4 M: 833-885 vs 1044-1066.
+    // NCF_BF16_KERNEL=ws|stream in the environment overrides the choice (tests run every batch size through both).
     bool ws = NCF_BF16_WS && B >= NCF_BF16_WS_MIN_PAIRS;
     if (const char* force = getenv("NCF_BF16_KERNEL")) {
         if (!strcmp(force, "ws")) ws = true;
