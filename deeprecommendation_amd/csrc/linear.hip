@@ -391,9 +391,12 @@ static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ld
     const int64_t tiles = (M + 31) / 32;
     const char* force = getenv("NCF_LINEAR_KERNEL");      // "rs" / "rsp": A/B and tests; unset: by shape
     // persistent row-streaming form: tall problems with K a multiple of 64 (bit-identical to the one-tile-per-wave form)
-    // (measured, tools/ab_linear.py: 1.1 M x 128 x 128 584 -> 488 us; 65 536 x 128 -> 256 83 -> 59 us; x 256 -> 128 74 -> 54 us;
-    // x 64 -> 128 48 -> 23 us, where the one-tile form splits K)
-    if (K % 64 == 0 && (force ? !strcmp(force, "rsp") : tiles >= 1024))
+    // Measured against the one-tile-per-wave form over the shapes of the hot path (tools/ab_linear.py, rs -> rsp):
+    // 1.1 M x 128 x 128 584 -> 488 us; 200 000 x 128 x 128 107 -> 95; 65 536 x 128 -> 256 83 -> 59, x 256 -> 128 74 -> 54,
+    // x 64 -> 128 48 -> 23; 32 768 x 128 x 128 67.5 -> 17.5 (the split-K form is slow at short K), x 256 -> 128 70 -> 28,
+    // x 128 -> 256 42 -> 30; 16 384 x 256 -> 128 35 -> 27; 4096..16 384 x 128 -> 256 37-39 -> 26-28.  The split-K form keeps
+    // deep-and-short problems (8192 x 256 -> 128: 18.7 vs 26.0 us; the 4096 x 2094 candidate Linear).
+    if (K % 64 == 0 && (force ? !strcmp(force, "rsp") : (tiles >= 512 || (K == 128 && tiles >= 128))))
         return launch_rsp<NT>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
     if constexpr (NT <= 4) {
         // Skinny and deep (the 4096 x 2094 -> 64 candidate Linear of AttentionNCF: 128 row tiles): one 32-column block

@@ -21,7 +21,9 @@ def per_launch(fn, reps=30):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-for M, K, N in ((1_100_000, 128, 128), (65536, 128, 256), (65536, 256, 128), (65536, 256, 256), (100_000, 128, 128), (16384, 2096, 64), (65536, 64, 128)):
+SHAPES = os.environ.get("AB_SHAPES")
+shapes = [tuple(int(v) for v in t.split("x")) for t in SHAPES.split(",")] if SHAPES else None
+for M, K, N in shapes or ((1_100_000, 128, 128), (65536, 128, 256), (65536, 256, 128), (65536, 256, 256), (100_000, 128, 128), (16384, 2096, 64), (65536, 64, 128)):
     x = torch.randn(M, K, device=dev, generator=g)
     w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
     b = torch.randn(N, device=dev, generator=g)
