@@ -711,17 +711,60 @@ typedef void (*fused_fn)(FusedArgs);
 #define NCF_SMALL_TILES 768   // below this many 32-pair tiles the 4-waves-per-tile kernel is used (measured crossover)
 #endif
 
+#ifndef NCF_HYBRID
+#define NCF_HYBRID 1          // ragged last round of the one-wave-per-tile kernel goes to the 4-waves-per-tile kernel
+#endif
+#ifndef NCF_HYBRID_MAX_PERMILLE
+#define NCF_HYBRID_MAX_PERMILLE 850   // ... when it fills less than this share of a round (above: one more full round is cheaper)
+#endif
+
+static int fused_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
 template <int K0, int N1, int N2>
 static void launch_inst(const FusedArgs& a, hipStream_t s) {
     const int64_t tiles = (a.B + 31) / 32;
+    auto launch_main = [&](const FusedArgs& x) {
+        const int64_t t = (x.B + 31) / 32;
+        hipLaunchKernelGGL((score_fused_f32_kernel<K0, N1, N2>), dim3((unsigned)((t + NCF_WG_WAVES - 1) / NCF_WG_WAVES)),
+                           dim3(NCF_WG_WAVES * 64), 0, s, x);
+    };
     if constexpr ((N1 / 32) % 4 == 0 && (N2 / 32) <= 4) {
-        if (tiles < NCF_SMALL_TILES) {
-            hipLaunchKernelGGL((score_fused_small_f32_kernel<K0, N1, N2>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-            return;
+        auto launch_small = [&](const FusedArgs& x) {
+            hipLaunchKernelGGL((score_fused_small_f32_kernel<K0, N1, N2>), dim3((unsigned)((x.B + 31) / 32)), dim3(256), 0, s, x);
+        };
+        if (tiles < NCF_SMALL_TILES) return launch_small(a);
+        // The main kernel's time is a staircase: one step (34.7 us for 128-256-128 on an MI355X) per ROUND of
+        // 4 x CUs tiles, whether the round is full or not; the small kernel is linear (1.22 us per 1024 pairs) and
+        // computes every pair in the same operation order, so a ragged tail can move to it without changing a bit.
+        // Measured (us, main | small): 16 384 pairs 35.8 | 22.3, 24 576: 35.9 | 31.5, 32 768: 38.0 | 42.0,
+        // 49 152: 68.3 | 59.9, 65 536: 69.5 | 78.1.  Identity ids (idx == NULL) cannot be offset: no split there.
+        const int64_t round = 4 * (int64_t)fused_num_cus();
+        const int64_t full = tiles / round, rem = tiles % round;
+        const bool ids_ok = a.idxA && (a.EA == K0 || a.idxB);
+        if (NCF_HYBRID && ids_ok && rem > 0 && rem * 1000 < round * NCF_HYBRID_MAX_PERMILLE) {
+            const int64_t split = full * round * 32;   // pairs handled by the full rounds
+            FusedArgs tail = a;
+            tail.idxA = a.idxA + split;
+            if (a.idxB) tail.idxB = a.idxB + split;
+            tail.out = a.out + split;
+            tail.B = a.B - split;
+            if (full > 0) {
+                FusedArgs head = a;
+                head.B = split;
+                launch_main(head);
+            }
+            return launch_small(tail);
         }
     }
-    const unsigned blocks = (unsigned)((tiles + NCF_WG_WAVES - 1) / NCF_WG_WAVES);
-    hipLaunchKernelGGL((score_fused_f32_kernel<K0, N1, N2>), dim3(blocks), dim3(NCF_WG_WAVES * 64), 0, s, a);
+    launch_main(a);
 }
 
 #define NCF_FUSED_INSTANCES(X) \

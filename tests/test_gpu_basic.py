@@ -473,6 +473,42 @@ def test_small_batch_kernel_is_bit_identical_to_main_kernel(native, gpu, E, hidd
     assert torch.equal(big.cpu(), ref)
 
 
+@pytest.mark.parametrize("B", [32768 + 1, 40000, 49152, 65536 + 31, 73729, 32768 + 28000])
+def test_ragged_last_round_split_is_bit_identical(native, gpu, B):
+    """A batch that does not fill its last round of the one-wave-per-tile kernel is split: full rounds on the main
+    kernel, the tail on the 4-waves-per-tile kernel (mlp_fused.hip launch_inst).  The split must not change a bit:
+    compare with the same pairs scored in 999-pair batches (small kernel only) and with the kernel-order C oracle,
+    and check that an out-of-range id in the tail still raises and reads as a zero row."""
+    from oracle import c_oracle
+    E, hidden = 64, [256, 128]
+    g = torch.Generator().manual_seed(B)
+    dims = [2 * E] + hidden + [1]
+    ta = torch.randn(900, E, generator=g) * 0.5
+    tb = torch.randn(400, E, generator=g) * 0.5
+    ia = torch.randint(0, 900, (B,), generator=g)
+    ib = torch.randint(0, 400, (B,), generator=g)
+    ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(len(dims) - 1)]
+    packed = native.PackedMLP([w.to(gpu) for w in ws], [b.to(gpu) for b in bs])
+    tag, tbg, iag, ibg = ta.to(gpu), tb.to(gpu), ia.to(gpu), ib.to(gpu)
+    whole = native.score_fused(tag, iag, tbg, ibg, packed)
+    assert whole.shape == (B, 1)
+    pieces = torch.cat([native.score_fused(tag, iag[s:s + 999].contiguous(), tbg, ibg[s:s + 999].contiguous(), packed)
+                        for s in range(0, B, 999)])
+    assert torch.equal(whole, pieces)
+    if B <= 49152:
+        assert torch.equal(whole.cpu(), c_oracle.score_fused_f32(ta, tb, ia, ib, ws, bs))
+    native.check_oob(gpu)
+    bad = iag.clone()
+    bad[B - 5] = 900
+    out = native.score_fused(tag, bad, tbg, ibg, packed)
+    with pytest.raises(IndexError):
+        native.check_oob(gpu)
+    zero_row = native.score_fused(torch.cat([tag, torch.zeros(1, E, device=gpu)]), bad, tbg, ibg, packed)
+    native.check_oob(gpu)
+    assert torch.equal(out, zero_row)
+
+
 @pytest.mark.parametrize("M,K,N,relu", [(20000, 256, 128, True), (16500, 64, 128, False), (300, 40, 64, True), (16384, 128, 256, False)])
 @pytest.mark.parametrize("kernel", ["rs", "rsp"])
 def test_linear_kernels_agree_with_float64(native, gpu, monkeypatch, M, K, N, relu, kernel):

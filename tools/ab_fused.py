@@ -31,7 +31,7 @@ def build_variant(i, flags):
 def main():
     variants = sys.argv[1:] or [""]
     dev = torch.device("cuda:0")
-    U, I, E, Bsz = 1_000_000, 100_000, 64, 65536
+    U, I, E, Bsz = 1_000_000, 100_000, 64, int(os.environ.get("AB_B", 65536))
     g = torch.Generator(device=dev).manual_seed(1)
     tu = torch.randn(U, E, device=dev, generator=g) * 0.05
     ti = torch.randn(I, E, device=dev, generator=g) * 0.05
