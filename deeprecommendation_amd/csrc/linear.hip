@@ -149,13 +149,14 @@ __device__ __forceinline__ void rs_mma(const RsFrag<NT>& f, f32x16 (&acc)[NT]) {
 }
 
 template <int NT, int KS, bool RELU>
-__global__ __launch_bounds__(256) void linear_rs_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+__global__ __launch_bounds__(KS > 4 ? KS * 64 : 256) void linear_rs_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                         int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
                                                         int64_t ldc, int64_t M, int K) {
-    __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 4 * NT * 16 * 64 : 4];
+    constexpr int WAVES = KS > 4 ? KS : 4;   // KS = 8 / 16: one tile per 512- / 1024-thread workgroup
+    __shared__ __attribute__((aligned(16))) float red[KS > 1 ? WAVES * NT * 16 * 64 : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t tile = (int64_t)blockIdx.x * (4 / KS) + wave / KS;
+    const int64_t tile = (int64_t)blockIdx.x * (WAVES / KS) + wave / KS;
     const int ks = wave % KS;
     // gridDim.y column blocks of 32*NT outputs each (skinny problems run narrower blocks to fill the chip)
     W += (int64_t)blockIdx.y * 32 * NT * ldw;
@@ -380,9 +381,10 @@ template <int NT, int KS>
 static void launch_rs(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                       int64_t M, int K, bool relu, hipStream_t s, int col_blocks = 1) {
     const int64_t tiles = (M + 31) / 32;
-    const dim3 grid((unsigned)((tiles + (4 / KS) - 1) / (4 / KS)), (unsigned)col_blocks);
-    if (relu) hipLaunchKernelGGL((linear_rs_kernel<NT, KS, true>), grid, dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
-    else hipLaunchKernelGGL((linear_rs_kernel<NT, KS, false>), grid, dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
+    constexpr int WAVES = KS > 4 ? KS : 4, TPB = WAVES / KS;
+    const dim3 grid((unsigned)((tiles + TPB - 1) / TPB), (unsigned)col_blocks);
+    if (relu) hipLaunchKernelGGL((linear_rs_kernel<NT, KS, true>), grid, dim3(WAVES * 64), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
+    else hipLaunchKernelGGL((linear_rs_kernel<NT, KS, false>), grid, dim3(WAVES * 64), 0, s, A, lda, W, ldw, bias, C, ldc, M, K);
 }
 
 template <int NT>
@@ -396,13 +398,23 @@ static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ld
     // x 64 -> 128 48 -> 23; 32 768 x 128 x 128 67.5 -> 17.5 (the split-K form is slow at short K), x 256 -> 128 70 -> 28,
     // x 128 -> 256 42 -> 30; 16 384 x 256 -> 128 35 -> 27; 4096..16 384 x 128 -> 256 37-39 -> 26-28.  The split-K form keeps
     // deep-and-short problems (8192 x 256 -> 128: 18.7 vs 26.0 us; the 4096 x 2094 candidate Linear).
-    if (K % 64 == 0 && (force ? !strcmp(force, "rsp") : (tiles >= 512 || (K == 128 && tiles >= 128))))
+    // Short K (<= 128) from 128 tiles: 4096 x 64 -> 128 18.3 -> 14.4 us, -> 256 28.1 -> 17.7, 16 384 x 64 -> 128 35.0 -> 14.4
+    // (splitting a K of 8 or 16 steps over 4 waves only adds the LDS reduction).
+    if (K % 64 == 0 && (force ? !strcmp(force, "rsp") : (tiles >= 512 || (K <= 128 && tiles >= 128))))
         return launch_rsp<NT>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
     if constexpr (NT <= 4) {
         // Skinny and deep (the 4096 x 2094 -> 64 candidate Linear of AttentionNCF: 128 row tiles): one 32-column block
         // per workgroup so that tiles * NT workgroups share the chip — the rows of A are re-read once per column block
         // (from L2), each wave's MFMA chain is NT times shorter; same split-K order, bit-identical results.
-        if (NT > 1 && tiles * NT <= 512 && K >= 512) return launch_rs<1, 4>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s, NT);
+        if (NT > 1 && tiles * NT <= 512 && K >= 512) {
+            // ... and with at most one such workgroup per CU, 8 K-slices (512 threads, two waves per SIMD) instead of 4:
+            // 4096 x 2094 -> 64: 36.5 -> 29.9 us, 2048 rows 27.1 -> 26.0; NOT beyond 256 workgroups (8192 rows: 48.8 -> 61.0,
+            // N = 128: 47.2 -> 55.5) and 16 slices lose everywhere (tools/ab_linear_env.py, NCF_LINEAR_KS=4|8 forces one)
+            const char* ksf = getenv("NCF_LINEAR_KS");
+            const bool ks8 = ksf ? atoi(ksf) == 8 : (tiles * NT <= 256 && K >= 1024);
+            if (ks8) return launch_rs<1, 8>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s, NT);
+            return launch_rs<1, 4>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s, NT);
+        }
         if (tiles <= 1024 && K >= 64) return launch_rs<NT, 4>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
         if (tiles <= 2048 && K >= 32) return launch_rs<NT, 2>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
     }

@@ -134,9 +134,9 @@ class AttentionNCF(_ScoringMixin, NCF):
         return '_cosine' if self.use_cos_sim_instead else f'_attNet{self.att_dense}'
 
     # ------------------------------------------------------------------------------------------ HIP scoring
-    def _att_split(self):
+    def _att_split(self, cache=None):
         """Contiguous halves of AttentionNet.0 split at the cat(candidate, rated) boundary (:176)."""
-        cache = self._refresh()
+        cache = self._refresh() if cache is None else cache
         if "att_split" not in cache:
             l0 = self.AttentionNet[0]
             IE = self.ItemEmbeddings[0].out_features
@@ -144,11 +144,11 @@ class AttentionNCF(_ScoringMixin, NCF):
             cache["att_split"] = (w[:, :IE].contiguous(), w[:, IE:].contiguous(), l0.bias.detach().contiguous())
         return cache["att_split"]
 
-    def precompute_catalog(self, rated_items: torch.Tensor):
+    def precompute_catalog(self, rated_items: torch.Tensor, cache=None):
         """Everything that depends only on the rated-item list: its embeddings, the rated half of the attention
         projection and the UserEmbeddings projection of the raw features.  Cached for the last list seen (serving
         scores one user against the whole catalogue, reference webapp/backend.py:78-121)."""
-        cache = self._refresh()
+        cache = self._refresh() if cache is None else cache
         key = (rated_items.data_ptr(), tuple(rated_items.shape), rated_items._version)
         hit = cache.get("catalog")
         if hit is not None and hit[0] == key:
@@ -159,7 +159,7 @@ class AttentionNCF(_ScoringMixin, NCF):
         if self.use_cos_sim_instead:
             pr = native.l2_normalize_rows(rated_emb)
         else:
-            _, wr, _ = self._att_split()
+            _, wr, _ = self._att_split(cache)
             pr = native.linear(rated_emb, wr, None)
         proj = native.linear(x, lu.weight.detach(), None)  # P = rated_items @ Wu^T ; bias added once per user row
         val = (rated_emb, pr, proj)
@@ -170,18 +170,18 @@ class AttentionNCF(_ScoringMixin, NCF):
         if not use_native(self):
             return self._forward_train(candidate_items, rated_items, user_matrix, return_attention_weights)
         require_gpu(candidate_items, rated_items)
+        cache = self._refresh()  # ONE parameter fingerprint per forward (it walks the module tree: ~12 us of host time)
         li, lu = self.ItemEmbeddings[0], self.UserEmbeddings[0]
         cand_emb = native.linear(candidate_items.float().contiguous(), li.weight.detach(), li.bias.detach())
-        rated_emb, pr, proj = self.precompute_catalog(rated_items)
+        rated_emb, pr, proj = self.precompute_catalog(rated_items, cache)
         ratings = user_matrix if isinstance(user_matrix, SparseRatings) else SparseRatings.from_dense(user_matrix)
         if self.use_cos_sim_instead:
             mode, pc, w1, b1 = native.ATT_COS, native.l2_normalize_rows(cand_emb), None, 0.0
         else:
-            wc, _, b0 = self._att_split()
+            wc, _, b0 = self._att_split(cache)
             pc = native.linear(cand_emb, wc, b0)
             if self.att_dense:
                 l1 = self.AttentionNet[-1]
-                cache = self._refresh()
                 if "att_out" not in cache:
                     cache["att_out"] = (l1.weight.detach().reshape(-1).contiguous(), float(l1.bias.detach().item()))
                 w1, b1 = cache["att_out"]
@@ -196,14 +196,14 @@ class AttentionNCF(_ScoringMixin, NCF):
                                               ratings.pair_row, proj, out_bias=lu.bias.detach(),
                                               return_weights=return_attention_weights)
             if return_attention_weights:
-                out = self._score(cand_emb, None, res[0], None)
+                out = self._score(cand_emb, None, res[0], None, cache=cache)
                 return out, ratings.expanded().to_dense(res[1])
-            return self._score(cand_emb, None, res, None)
+            return self._score(cand_emb, None, res, None, cache=cache)
         if shared:
             ratings = ratings.expanded()
         user_emb, wts = native.attn_forward(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val, proj,
                                             out_bias=lu.bias.detach())
-        out = self._score(cand_emb, None, user_emb, None)  # cat(candidate_emb, user_emb): :219
+        out = self._score(cand_emb, None, user_emb, None, cache=cache)  # cat(candidate_emb, user_emb): :219
         if return_attention_weights:
             return out, ratings.to_dense(wts)
         return out

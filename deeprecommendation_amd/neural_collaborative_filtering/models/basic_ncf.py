@@ -46,25 +46,27 @@ class _ScoringMixin:
             self._native_ver = ver
         return self._native_cache
 
-    def _table(self, name: str, lin: nn.Linear) -> torch.Tensor:
-        cache = self._refresh()
+    # Every helper below takes the dict returned by ONE `_refresh()` per forward: the parameter fingerprint walks the
+    # module tree (≈ 12 µs on the host) and a forward used to pay it three times (49 µs per call, measured).
+    def _table(self, name: str, lin: nn.Linear, cache=None) -> torch.Tensor:
+        cache = self._refresh() if cache is None else cache
         if name not in cache:
             with torch.no_grad():
                 # row i = W[:, i] + b : exactly what Linear(onehot(i)) computes (one fp32 rounding)
                 cache[name] = (lin.weight.detach().t().contiguous() + lin.bias.detach()).to(self.scoring_dtype).contiguous()
         return cache[name]
 
-    def _dense_weight(self, name: str, lin: nn.Linear) -> torch.Tensor:
+    def _dense_weight(self, name: str, lin: nn.Linear, cache=None) -> torch.Tensor:
         """Row-contiguous [E, num_ids] copy of an embedding weight for the dense-profile GEMM (the parameter itself is
         stored id-major, util.row_major_embedding_); cached per weight version."""
-        cache = self._refresh()
+        cache = self._refresh() if cache is None else cache
         key = "dense_w::" + name
         if key not in cache:
             cache[key] = lin.weight.detach().contiguous()
         return cache[key]
 
-    def _packed_mlp(self, name: str = "MLP"):
-        cache = self._refresh()
+    def _packed_mlp(self, name: str = "MLP", cache=None):
+        cache = self._refresh() if cache is None else cache
         key = "packed::" + name
         if key not in cache:
             lins = mlp_linears(getattr(self, name))
@@ -76,10 +78,10 @@ class _ScoringMixin:
                 cache[key] = None
         return cache[key]
 
-    def _folded(self, tabA, tabB, mlp_name):
+    def _folded(self, tabA, tabB, mlp_name, cache=None):
         """(PA, PB, packed tail MLP) for the folded path, cached per weight version and table pair; None if the MLP
         shape has no folded kernel."""
-        cache = self._refresh()
+        cache = self._refresh() if cache is None else cache
         key = ("folded", mlp_name, tabA.data_ptr(), tabB.data_ptr(), tuple(tabA.shape), tuple(tabB.shape))
         if key not in cache:
             lins = mlp_linears(getattr(self, mlp_name))
@@ -97,16 +99,16 @@ class _ScoringMixin:
         hit = cache[key]
         return None if hit is None else hit[:3]
 
-    def _score(self, tabA, idxA, tabB, idxB, mlp_name="MLP"):
+    def _score(self, tabA, idxA, tabB, idxB, mlp_name="MLP", cache=None):
         """gather(A) ‖ gather(B) -> MLP -> (B,1): fused kernel when the shape has an instance, else K1 + K2."""
         EA = tabA.shape[1]
         EB = 0 if tabB is None else tabB.shape[1]
         if self.fold_first_layer and tabB is not None and tabA.dtype == torch.float32:
-            folded = self._folded(tabA, tabB, mlp_name)
+            folded = self._folded(tabA, tabB, mlp_name, cache)
             if folded is not None:
                 PA, PB, tail = folded
                 return native.score_folded(PA, idxA, PB, idxB, tail)
-        packed = self._packed_mlp(mlp_name)
+        packed = self._packed_mlp(mlp_name, cache)
         if packed is not None and tabA.dtype == packed.dtype and packed.supports(EA, EB):
             return native.score_fused(tabA, idxA, tabB, idxB, packed)
         if tabA.dtype != torch.float32:
@@ -137,13 +139,14 @@ class BasicNCF(_ScoringMixin, NCF):
         if not use_native(self):
             return self._forward_train(X_user, X_item, indexed)
         require_gpu(X_user, X_item)
+        cache = self._refresh()
         if indexed:
-            return self._score(self._table("user", self.user_embeddings[0]), X_user.contiguous(),
-                               self._table("item", self.item_embeddings[0]), X_item.contiguous())
+            return self._score(self._table("user", self.user_embeddings[0], cache), X_user.contiguous(),
+                               self._table("item", self.item_embeddings[0], cache), X_item.contiguous(), cache=cache)
         ue, ie = self.user_embeddings[0], self.item_embeddings[0]
-        u = native.linear(X_user.float().contiguous(), self._dense_weight("user", ue), ue.bias.detach())
-        i = native.linear(X_item.float().contiguous(), self._dense_weight("item", ie), ie.bias.detach())
-        return self._score(u, None, i, None)  # cat(user, item): basic_ncf.py:40
+        u = native.linear(X_user.float().contiguous(), self._dense_weight("user", ue, cache), ue.bias.detach())
+        i = native.linear(X_item.float().contiguous(), self._dense_weight("item", ie, cache), ie.bias.detach())
+        return self._score(u, None, i, None, cache=cache)  # cat(user, item): basic_ncf.py:40
 
     def _forward_train(self, X_user, X_item, indexed):
         """Training step (dropout active, autograd recording).  On CUDA tensors the gather and the Linear(+ReLU) layers run

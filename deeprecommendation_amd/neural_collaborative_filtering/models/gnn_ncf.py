@@ -319,9 +319,9 @@ class GraphNCF(_ScoringMixin, GNN_NCF):
                 native.linear(feats.float().contiguous(), lin.weight.detach(), lin.bias.detach(), out=x0[lo:hi])
         return x0
 
-    def propagate_all(self, graph: GraphData) -> torch.Tensor:
+    def propagate_all(self, graph: GraphData, cache=None) -> torch.Tensor:
         """combined_graph_emb of gnn_ncf.py:336-351 for the whole graph (cached per graph + weights)."""
-        cache = self._refresh()
+        cache = self._refresh() if cache is None else cache
         key = ("combined", id(graph))
         if key in cache:
             return cache[key][1]
@@ -351,10 +351,11 @@ class GraphNCF(_ScoringMixin, GNN_NCF):
             return self._forward_train(graph, userIds, itemIds, device, mask_targets)
         require_gpu(userIds, itemIds)
         graph = graph.to(userIds.device)
-        combined = self.propagate_all(graph)
+        cache = self._refresh()  # one parameter fingerprint per forward
+        combined = self.propagate_all(graph, cache)
         userIds, itemIds = userIds.long().contiguous(), itemIds.long().contiguous()
         if self.MLP is not None:
-            return self._score(combined, itemIds, combined, userIds)  # cat(item, user): gnn_ncf.py:361
+            return self._score(combined, itemIds, combined, userIds, cache=cache)  # cat(item, user): gnn_ncf.py:361
         return native.gather_dot(combined, userIds, combined, itemIds)  # gnn_ncf.py:365
 
     # ------------------------------------------------------------------------------------------ torch training path

@@ -30,10 +30,11 @@ class MF(_ScoringMixin, NCF):
                 u, i = self.user_embeddings(X_user), self.item_embeddings(X_item)
             return torch.bmm(u.unsqueeze(1), i.unsqueeze(2)).view(-1, 1)
         require_gpu(X_user, X_item)
+        cache = self._refresh()  # one parameter fingerprint per forward
         if indexed:
-            return native.gather_dot(self._table("user", self.user_embeddings[0]), X_user.contiguous(),
-                                     self._table("item", self.item_embeddings[0]), X_item.contiguous())
+            return native.gather_dot(self._table("user", self.user_embeddings[0], cache), X_user.contiguous(),
+                                     self._table("item", self.item_embeddings[0], cache), X_item.contiguous())
         ue, ie = self.user_embeddings[0], self.item_embeddings[0]
-        u = native.linear(X_user.float().contiguous(), self._dense_weight("user", ue), ue.bias.detach())
-        i = native.linear(X_item.float().contiguous(), self._dense_weight("item", ie), ie.bias.detach())
+        u = native.linear(X_user.float().contiguous(), self._dense_weight("user", ue, cache), ue.bias.detach())
+        i = native.linear(X_item.float().contiguous(), self._dense_weight("item", ie, cache), ie.bias.detach())
         return native.gather_dot(u, None, i, None, B=u.shape[0])

@@ -55,7 +55,7 @@ def load_model(file, ModelClass=None, map_location="cpu", **kargs):
 def params_version(module: nn.Module) -> tuple:
     """Cheap fingerprint of a module's parameters: changes whenever a parameter is updated in place, re-assigned
     or moved.  Used to invalidate the derived inference tensors (embedding tables, packed MLP weights)."""
-    return tuple((p.data_ptr(), p._version, str(p.device)) for p in module.parameters())
+    return tuple((p.data_ptr(), p._version, p.device) for p in module.parameters())
 
 
 def use_native(module: nn.Module, *tensors) -> bool:

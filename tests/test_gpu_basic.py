@@ -524,3 +524,23 @@ def test_linear_kernels_agree_with_float64(native, gpu, monkeypatch, M, K, N, re
     if relu:
         ref = torch.relu(ref)
     assert_close(out, ref.float())
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 2094, 64), (1000, 2094, 64), (4100, 1030, 128), (33, 2094, 64)])
+@pytest.mark.parametrize("ks", ["4", "8", None])
+def test_skinny_split_k_widths_agree_with_float64(native, gpu, monkeypatch, M, K, N, ks):
+    """Skinny-deep Linear (AttentionNCF's F = 2094 candidate layer): K split over 4 or 8 waves of a workgroup, partial
+    sums added through LDS in slice order; forced either way and by the shape rule, against a float64 product (K % 8 != 0
+    tail, ragged last row block)."""
+    if ks is None:
+        monkeypatch.delenv("NCF_LINEAR_KS", raising=False)
+    else:
+        monkeypatch.setenv("NCF_LINEAR_KS", ks)
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    out = native.linear(x.to(gpu), w.to(gpu), b.to(gpu))
+    again = native.linear(x.to(gpu), w.to(gpu), b.to(gpu))
+    assert torch.equal(out, again)  # slice order is fixed: run-to-run identical
+    assert_close(out, (x.double() @ w.double().t() + b.double()).float())
