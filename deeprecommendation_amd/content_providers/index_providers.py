@@ -14,8 +14,40 @@ from ..neural_collaborative_filtering.models.attention_ncf import SparseRatings
 from ..neural_collaborative_filtering.models.gnn_ncf import GraphData
 
 
+_LUT_MIN_QUERY = 4096          # below this many ids a binary search is cheaper than building / touching a table
+_LUT_MAX_SLOTS = 1 << 27       # 1 GiB of int64 at most
+_luts = {}                     # id(sorted array) -> (array, lo, table): rank of every integer id in [lo, hi], -1 if absent
+
+
+def _lut_for(sorted_ids: np.ndarray):
+    hit = _luts.get(id(sorted_ids))
+    if hit is not None and hit[0] is sorted_ids:
+        return hit[1], hit[2]
+    if len(sorted_ids) == 0 or not np.issubdtype(sorted_ids.dtype, np.integer):
+        return None
+    lo, hi = int(sorted_ids[0]), int(sorted_ids[-1])
+    slots = hi - lo + 1
+    if slots > _LUT_MAX_SLOTS or slots > 16 * len(sorted_ids) + 1024:
+        return None  # sparse id space: keep the binary search
+    table = np.full(slots, -1, dtype=np.int64)
+    table[sorted_ids - lo] = np.arange(len(sorted_ids), dtype=np.int64)
+    _luts[id(sorted_ids)] = (sorted_ids, lo, table)
+    return lo, table
+
+
 def _positions(sorted_ids: np.ndarray, ids) -> np.ndarray:
+    """Rank of each id among the sorted unique ids (LabelBinarizer's ``classes_`` order); KeyError for an unknown id.
+    Whole-file queries over a dense integer id space go through a direct table (one gather per id; measured at 8 M
+    queries into 1 M ids: 1.98 s with the binary search — 98 % of a device-resident evaluation pass)."""
     ids = np.atleast_1d(np.asarray(ids))
+    if len(ids) >= _LUT_MIN_QUERY and np.issubdtype(ids.dtype, np.integer):
+        lut = _lut_for(sorted_ids)
+        if lut is not None:
+            lo, table = lut
+            if int(ids.min()) >= lo and int(ids.max()) < lo + len(table):   # else: the search below names the culprits
+                pos = table[ids - lo] if lo else table[ids]
+                if int(pos.min()) >= 0:
+                    return pos
     pos = np.searchsorted(sorted_ids, ids)
     bad = (pos >= len(sorted_ids)) | (sorted_ids[np.minimum(pos, len(sorted_ids) - 1)] != ids)
     if bad.any():
@@ -51,6 +83,28 @@ class IndexProvider(ContentProvider):
 
     def get_item_feature_dim(self):
         return self.get_num_items()
+
+    def device_lookup(self, device):
+        """id -> position ON THE GPU: ``f(user_ids, item_ids) -> (user_pos, item_pos)`` over int64 device tensors, or
+        None when an id space is too sparse for a direct table.  A host core resolves ~5 M random ids per second
+        (binary search or table alike: it is cache-miss bound); the same gather is microseconds on the GPU, so whole-file
+        evaluation uploads RAW ids.  An unknown id maps to -1, which every HIP kernel reports through the out-of-range
+        flag (IndexError from native.check_oob) instead of the host path's KeyError."""
+        cache = self.__dict__.setdefault("_device_luts", {})
+        key = str(device)
+        if key not in cache:
+            luts = [_lut_for(self.all_user_ids), _lut_for(self.all_item_ids)]
+            cache[key] = None if any(l is None for l in luts) else [(lo, torch.from_numpy(t).to(device)) for lo, t in luts]
+        tabs = cache[key]
+        if tabs is None:
+            return None
+
+        def one(ids, lo, table):
+            rel = ids - lo
+            pos = table[rel.clamp(0, table.numel() - 1)]
+            return torch.where((rel >= 0) & (rel < table.numel()), pos, torch.full_like(pos, -1))
+
+        return lambda user_ids, item_ids: (one(user_ids, *tabs[0]), one(item_ids, *tabs[1]))
 
 
 class OneHotProvider(IndexProvider):

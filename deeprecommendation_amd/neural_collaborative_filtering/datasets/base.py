@@ -32,6 +32,19 @@ class PointwiseDataset(Dataset):
     def use_collate(self):
         return None
 
+    def resident_inputs(self, device=None):
+        """Whole-file model inputs as host tensors, in sample order, for datasets whose batch is a pure function of the
+        sample rows (index ids): ``(tensors, targets, on_device)``.  ``on_device`` is None or a function applied to the
+        uploaded chunk ``(*tensors[s:e]) -> inputs`` on the GPU (raw ids -> table positions); then
+        ``do_forward(model, (*inputs[s:e], y[s:e]), ...)`` equals the DataLoader batch [s, e).  ``None`` (default): batches
+        need the collate (dense / per-batch profiles).  eval_model uses it to skip the per-sample Python loop."""
+        return None
+
+    def _targets(self):
+        import torch
+        r = self._r / 5.0 if self.use_bce_loss else self._r
+        return torch.as_tensor(r, dtype=torch.float32)
+
     @staticmethod
     def do_forward(*args, **kwargs):
         raise NotImplementedError

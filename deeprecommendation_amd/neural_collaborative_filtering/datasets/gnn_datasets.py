@@ -16,6 +16,9 @@ class GraphPointwiseDataset(PointwiseDataset):
     def __getitem__(self, item):
         return self._unode[item], self._inode[item], self._r[item]
 
+    def resident_inputs(self, device=None):
+        return (torch.as_tensor(self._unode, dtype=torch.int64), torch.as_tensor(self._inode, dtype=torch.int64)), self._targets(), None
+
     def get_graph(self, device):
         return self.gcp.get_graph().to(device)
 

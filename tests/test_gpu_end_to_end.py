@@ -128,3 +128,68 @@ def test_hip_graph_replay_matches_eager(gpu):
         i1 = torch.randint(0, 700, (4096,), generator=g).to(gpu)
         assert torch.equal(bm(u1, i1), gb(u1, i1).clone())
         assert torch.equal(bm(u0, i0), gb(u0, i0).clone())
+
+
+@pytest.mark.parametrize("n,batch", [(10_000, 512), (70_000, 1000), (513, 512), (5, 64)])
+def test_resident_eval_equals_dataloader_eval(gpu, monkeypatch, n, batch):
+    """eval_model's device-resident path (ids uploaded in chunks on a copy stream, loss and predictions kept on the GPU)
+    against the reference-shaped DataLoader loop: same batches through the same do_forward -> identical predictions and
+    the same per-batch loss sums; several upload chunks (chunk = 4 batches here) and a ragged last chunk / batch."""
+    from deeprecommendation_amd.content_providers.index_providers import IndexProvider
+    from deeprecommendation_amd.neural_collaborative_filtering import eval as E
+    from deeprecommendation_amd.neural_collaborative_filtering.datasets.fixed_datasets import FixedPointwiseDataset
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    monkeypatch.setattr(E, "RESIDENT_CHUNK_BATCHES", 4)
+    rng = np.random.default_rng(n + batch)
+    U, I = 3000, 800
+    frame = pd.DataFrame({"userId": rng.integers(1, U + 1, n), "movieId": rng.integers(1, I + 1, n),
+                          "rating": rng.integers(1, 11, n) * 0.5})
+    ds = FixedPointwiseDataset(frame, IndexProvider(np.arange(1, U + 1), np.arange(1, I + 1)))
+    torch.manual_seed(0)
+    m = BasicNCF(item_dim=I, user_dim=U, item_emb=64, user_emb=64, mlp_dense_layers=[256, 128]).to(gpu)
+    fast = E.eval_model(m, ds, batch_size=batch, device=gpu, resident=True)
+    slow = E.eval_model(m, ds, batch_size=batch, device=gpu, resident=False)
+    assert np.array_equal(fast["predictions"], slow["predictions"])
+    assert abs(fast["mse"] - slow["mse"]) <= 1e-12 * slow["mse"]
+    for k in (5, 10, 20):
+        assert np.isclose(fast[f"ndcg@{k}"], slow[f"ndcg@{k}"], rtol=0, atol=0, equal_nan=True)  # nan: no user with 2+ rows
+
+
+def test_resident_eval_graph_dataset_and_refusals(gpu):
+    from deeprecommendation_amd.content_providers.index_providers import IndexGraphProvider, OneHotProvider
+    from deeprecommendation_amd.neural_collaborative_filtering.datasets.fixed_datasets import FixedPointwiseDataset
+    from deeprecommendation_amd.neural_collaborative_filtering.datasets.gnn_datasets import GraphPointwiseDataset
+    from deeprecommendation_amd.neural_collaborative_filtering.eval import eval_model
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphNCF
+    rng = np.random.default_rng(5)
+    key = np.unique(rng.integers(0, 150, 4000) * 1000 + rng.integers(0, 50, 4000))
+    users, items = key // 1000 + 1, key % 1000 + 1
+    ratings = rng.integers(1, 11, len(key)) * 0.5
+    gp = IndexGraphProvider(np.arange(1, 151), np.arange(1, 51), users, items, ratings)
+    test = pd.DataFrame({"userId": users[::2], "movieId": items[::2], "rating": ratings[::2]})
+    ds = GraphPointwiseDataset(test, gp)
+    torch.manual_seed(2)
+    m = GraphNCF(item_dim=50, user_dim=150, num_gnn_layers=2, hetero=False, node_emb=64, mlp_dense_layers=[128]).to(gpu)
+    fast = eval_model(m, ds, batch_size=100, device=gpu, resident=True)
+    slow = eval_model(m, ds, batch_size=100, device=gpu, resident=False)
+    assert np.array_equal(fast["predictions"], slow["predictions"]) and abs(fast["mse"] - slow["mse"]) <= 1e-12 * slow["mse"]
+    # dense one-hot profiles have no resident form: auto falls back to the loader, an explicit request is refused
+    dense = FixedPointwiseDataset(test, OneHotProvider(np.arange(1, 151), np.arange(1, 51)))
+    assert dense.resident_inputs() is None
+    b = BasicNCF(item_dim=50, user_dim=150, item_emb=32, user_emb=32, mlp_dense_layers=[128]).to(gpu)
+    eval_model(b, dense, batch_size=100, device=gpu)
+    with pytest.raises(ValueError):
+        eval_model(b, dense, batch_size=100, device=gpu, resident=True)
+    # an id the provider does not know: KeyError from the host lookup (loader path), IndexError from the kernels' out-of-range
+    # flag when the lookup runs on the GPU (resident path) — never a silent score
+    from deeprecommendation_amd.content_providers.index_providers import IndexProvider
+    n = 6000
+    frame = pd.DataFrame({"userId": rng.integers(1, 151, n), "movieId": rng.integers(1, 51, n), "rating": np.full(n, 3.0)})
+    frame.loc[n - 3, "userId"] = 999
+    bad = FixedPointwiseDataset(frame, IndexProvider(np.arange(1, 151), np.arange(1, 51)))
+    b2 = BasicNCF(item_dim=50, user_dim=150, item_emb=64, user_emb=64, mlp_dense_layers=[128]).to(gpu)
+    with pytest.raises(KeyError):
+        eval_model(b2, bad, batch_size=512, device=gpu, resident=False)
+    with pytest.raises(IndexError):
+        eval_model(b2, bad, batch_size=512, device=gpu, resident=True)

@@ -235,3 +235,44 @@ def test_gpu_only_helpers_fail_loudly_on_cpu():
             GraphedForward(lambda x: x, [torch.zeros(2)])
         with pytest.raises(RuntimeError):
             native.group_pairs(torch.zeros(4, dtype=torch.int64), 2, 8)
+
+
+def test_resident_inputs_match_the_dataloader_batches():
+    """Dataset.resident_inputs() (what eval_model keeps on the GPU) == the concatenation of the DataLoader's collated
+    batches, for index providers and graph datasets; dense-profile providers have none; BCE targets are scaled alike."""
+    import pandas as pd
+    from torch.utils.data import DataLoader
+    from deeprecommendation_amd.content_providers.index_providers import IndexGraphProvider, IndexProvider, OneHotProvider
+    from deeprecommendation_amd.neural_collaborative_filtering.datasets.fixed_datasets import FixedPointwiseDataset
+    from deeprecommendation_amd.neural_collaborative_filtering.datasets.gnn_datasets import GraphPointwiseDataset
+    rng = np.random.default_rng(0)
+    n = 257
+    frame = pd.DataFrame({"userId": rng.integers(10, 60, n) * 3, "movieId": rng.integers(1, 30, n) * 7, "rating": rng.integers(1, 11, n) * 0.5})
+    users, items = np.arange(10, 60) * 3, np.arange(1, 30) * 7
+    for ds in (FixedPointwiseDataset(frame, IndexProvider(users, items)),
+               GraphPointwiseDataset(frame, IndexGraphProvider(users, items, frame["userId"].values, frame["movieId"].values, frame["rating"].values))):
+        (u, i), y, on_device = ds.resident_inputs()
+        assert on_device is None  # no device given: positions resolved on the host
+        batches = list(DataLoader(ds, batch_size=50, collate_fn=ds.use_collate()))
+        assert torch.equal(u, torch.cat([b[0] for b in batches])) and torch.equal(i, torch.cat([b[1] for b in batches]))
+        assert torch.equal(y, torch.cat([b[2] for b in batches])) and u.dtype == torch.int64 and y.dtype == torch.float32
+    assert FixedPointwiseDataset(frame, OneHotProvider(users, items)).resident_inputs() is None
+    bce = FixedPointwiseDataset(frame, IndexProvider(users, items))
+    bce.use_bce_loss = True
+    assert torch.allclose(bce.resident_inputs()[1], torch.as_tensor(frame["rating"].values / 5.0, dtype=torch.float32))
+    # the on-GPU id lookup (run here on the CPU device): raw ids -> the same positions; unknown ids -> -1
+    prov = IndexProvider(users, items)
+    f = prov.device_lookup(torch.device("cpu"))
+    raw = FixedPointwiseDataset(frame, prov).resident_inputs(torch.device("cpu"))
+    assert raw[2] is not None and torch.equal(raw[0][0], torch.as_tensor(frame["userId"].values))
+    up, ip = raw[2](*raw[0])
+    assert torch.equal(up, torch.from_numpy(prov.get_user_profile(frame["userId"].values)))
+    assert torch.equal(ip, torch.from_numpy(prov.get_item_profile(frame["movieId"].values)))
+    up, ip = f(torch.tensor([30, 31, 29, 10 ** 9, -7]), torch.tensor([7, 8, 0, 203, 210]))
+    assert up.tolist() == [0, -1, -1, -1, -1] and ip.tolist() == [0, -1, -1, 28, -1]
+    sparse = IndexProvider(np.array([1, 10 ** 9]), items)
+    assert sparse.device_lookup(torch.device("cpu")) is None
+    from deeprecommendation_amd.neural_collaborative_filtering.eval import eval_model
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    with pytest.raises(ValueError):
+        eval_model(BasicNCF(item_dim=29, user_dim=50, item_emb=8, user_emb=8, mlp_dense_layers=[16]), bce, 32, device="cpu", resident=True)
