@@ -212,6 +212,18 @@ class SparseDynamicProvider(DynamicContentProvider):
     def get_item_feature_dim(self):
         return self.features.shape[1]
 
+    def device_state(self, device):
+        """Everything the collate reads, resident on ``device`` (cached): see _DynamicDeviceState.  None when an id space
+        is not a dense integer range."""
+        cache = self.__dict__.setdefault("_device_states", {})
+        key = str(device)
+        if key not in cache:
+            try:
+                cache[key] = _DynamicDeviceState(self, device)
+            except ValueError:
+                cache[key] = None
+        return cache[key]
+
     def collate_interacted_items(self, batch, for_ranking: bool, ignore_ratings=False):
         users, cand, third = zip(*batch)
         cand_ids = np.asarray(cand)
@@ -236,3 +248,68 @@ class SparseDynamicProvider(DynamicContentProvider):
                                 pair_row=torch.as_tensor(pair_row, dtype=torch.int64))
         user_matrix = ratings if self.sparse else ratings.to_dense(ratings.val)
         return cand_ids, rated_ids, candidate_items, self.get_item_profile(rated_ids), user_matrix, targets_or_items2
+
+
+class _DynamicDeviceState:
+    """SparseDynamicProvider on the GPU: the (I, F) feature table, id -> position tables, and EVERY user's rated set as
+    one CSR (row = user position, col = position in the whole sorted catalogue, val = rating - (mean + 2.5)/2, zeros
+    dropped — the rows ``collate_interacted_items`` builds, against the full catalogue instead of the batch's union of
+    rated items: columns of items nobody in the batch rated are masked out by the reference anyway, attention_ncf.py:158).
+    ``batch`` assembles the collate's 6-tuple from raw id tensors with two gathers; nothing is rebuilt per batch, and
+    since ``rated_items`` is the same tensor every time the model's catalogue projections are computed once."""
+
+    def __init__(self, prov, device):
+        self.device = torch.device(device)
+        uid = np.asarray(list(prov.user_pos.keys()))
+        upos = np.asarray(list(prov.user_pos.values()), dtype=np.int64)
+        if not (np.issubdtype(uid.dtype, np.integer) and np.issubdtype(prov.item_ids.dtype, np.integer)) or len(uid) == 0:
+            raise ValueError("non-integer ids")
+        ilut = _lut_for(prov.item_ids)
+        order = np.argsort(uid)
+        self._sorted_uid = uid[order]      # kept alive: _lut_for caches by object identity
+        ulut = _lut_for(self._sorted_uid)
+        if ilut is None or ulut is None:
+            raise ValueError("sparse id space")
+        utable = np.where(ulut[1] >= 0, upos[order][np.maximum(ulut[1], 0)], -1)   # rank among sorted ids -> provider position
+        self.user_lo, self.user_table = ulut[0], torch.from_numpy(utable).to(self.device)
+        self.item_lo, self.item_table = ilut[0], torch.from_numpy(ilut[1]).to(self.device)
+        self.features = prov.features.to(self.device).contiguous()
+        n_users = len(prov.user_rated_items)
+        counts = np.zeros(n_users, dtype=np.int64)
+        cols, vals = [], []
+        for p in range(n_users):
+            c = _positions(prov.item_ids, prov.user_rated_items[p]) if len(prov.user_rated_items[p]) else np.zeros(0, np.int64)
+            v = (prov.user_ratings[p] - (prov.user_mean[p] + 2.5) / 2).astype(np.float32)
+            keep = v != 0
+            cols.append(c[keep]); vals.append(v[keep]); counts[p] = int(keep.sum())
+        rowptr = np.zeros(n_users + 1, dtype=np.int64)
+        np.cumsum(counts, out=rowptr[1:])
+        self.rowptr = torch.from_numpy(rowptr).to(self.device)
+        self.col = torch.from_numpy(np.concatenate(cols).astype(np.int32) if cols else np.zeros(0, np.int32)).to(self.device)
+        self.val = torch.from_numpy(np.concatenate(vals) if vals else np.zeros(0, np.float32)).to(self.device)
+        self.num_items = len(prov.item_ids)
+
+    def _lookup(self, ids, lo, table):
+        rel = ids - lo
+        inside = (rel >= 0) & (rel < table.numel())
+        pos = torch.where(inside, table[rel.clamp(0, table.numel() - 1)], torch.full_like(rel, -1))
+        bad = pos < 0
+        if ids.is_cuda:
+            from .. import native
+            native._oob_flag(ids.device).add_(bad.any().to(torch.int32))   # sticky: IndexError at the next check_oob, no sync here
+        elif bool(bad.any()):
+            raise KeyError(f"unknown id(s): {ids[bad][:5].tolist()}")
+        return pos.clamp_min(0)
+
+    def positions(self, users, cands):
+        """Raw id tensors -> (user position, catalogue position); done once per uploaded CHUNK of batches."""
+        return self._lookup(users, self.user_lo, self.user_table), self._lookup(cands, self.item_lo, self.item_table)
+
+    def batch_at(self, upos, cpos, y, pairs_per_row_hint=None):
+        """The collate's 6-tuple for one batch of positions (cand_ids carries catalogue positions, rated_ids is None: the
+        rated list is the whole catalogue in provider order)."""
+        ratings = SparseRatings(self.rowptr, self.col, self.val, self.num_items, pair_row=upos, pairs_per_row_hint=pairs_per_row_hint)
+        return cpos, None, self.features.index_select(0, cpos), self.features, ratings, y
+
+    def batch(self, users, cands, y, pairs_per_row_hint=None):
+        return self.batch_at(*self.positions(users, cands), y, pairs_per_row_hint)

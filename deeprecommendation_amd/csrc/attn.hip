@@ -661,7 +661,9 @@ extern "C" int ncf_attn_forward_grouped(int mode, const float* pc, int64_t ldpc,
     const bool fvec = Fdim % 4 == 0 && ldfeat % 4 == 0;
     const int pieces_per_thread = (64 * (A / 4 + (fvec ? Fdim / 4 : 0)) + 511) / 512;   // <= 16 for A, Fdim <= 256
     hipStream_t s = (hipStream_t)stream;
-    const unsigned blocks = (unsigned)((B + pairs_per_wg - 1) / pairs_per_wg + R);   // upper bound on sum_r ceil(n_r / ppw)
+    // upper bound on sum_r ceil(n_r / ppw): every non-empty row adds at most one partly filled workgroup, and at most
+    // min(R, B) rows are non-empty (R may be a whole user base with B pairs of a few users: device-resident evaluation)
+    const unsigned blocks = (unsigned)((B + pairs_per_wg - 1) / pairs_per_wg + (R < B ? R : B));
 #define LAUNCH1(M, F, P)                                                                                                          \
     do {                                                                                                                       \
         if (lds > 64 * 1024 &&                                                                                                 \

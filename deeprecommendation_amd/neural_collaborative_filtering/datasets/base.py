@@ -6,6 +6,15 @@ from torch import nn
 from torch.utils.data import Dataset
 
 
+class ResidentInputs:
+    """Whole-file model inputs for eval_model's device-resident loop: host ``tensors`` (sample order) + ``targets``;
+    ``on_chunk(*device_tensors) -> inputs`` runs once per uploaded chunk (raw ids -> table positions), ``on_batch(*inputs,
+    y) -> batch`` builds the tuple ``do_forward`` receives (default: ``(*inputs, y)``)."""
+
+    def __init__(self, tensors, targets, on_chunk=None, on_batch=None):
+        self.tensors, self.targets, self.on_chunk, self.on_batch = tuple(tensors), targets, on_chunk, on_batch
+
+
 class PointwiseDataset(Dataset):
     def __init__(self, file_or_frame, use_bce_loss=False):
         self.samples = file_or_frame if isinstance(file_or_frame, pd.DataFrame) else pd.read_csv(str(file_or_frame) + '.csv')
@@ -32,12 +41,10 @@ class PointwiseDataset(Dataset):
     def use_collate(self):
         return None
 
-    def resident_inputs(self, device=None):
-        """Whole-file model inputs as host tensors, in sample order, for datasets whose batch is a pure function of the
-        sample rows (index ids): ``(tensors, targets, on_device)``.  ``on_device`` is None or a function applied to the
-        uploaded chunk ``(*tensors[s:e]) -> inputs`` on the GPU (raw ids -> table positions); then
-        ``do_forward(model, (*inputs[s:e], y[s:e]), ...)`` equals the DataLoader batch [s, e).  ``None`` (default): batches
-        need the collate (dense / per-batch profiles).  eval_model uses it to skip the per-sample Python loop."""
+    def resident_inputs(self, device=None, batch_size=None):
+        """A ResidentInputs for datasets whose batch is a pure function of the sample rows (index ids), such that
+        ``do_forward(model, batch, ...)`` over its batches equals the DataLoader loop; ``None`` (default): batches need the
+        host collate (dense profiles).  eval_model uses it to skip the per-sample Python loop."""
         return None
 
     def _targets(self):

@@ -3,7 +3,7 @@ The collate emits int64 tensors when the provider returns positions (table path)
 import numpy as np
 import torch
 
-from .base import PointwiseDataset
+from .base import PointwiseDataset, ResidentInputs
 
 
 def _to_tensor(x):
@@ -25,15 +25,15 @@ class FixedPointwiseDataset(PointwiseDataset):
 
         return custom_collate
 
-    def resident_inputs(self, device=None):
+    def resident_inputs(self, device=None, batch_size=None):
         cp = self.content_provider
         probe_u, probe_i = np.asarray(cp.get_user_profile(userID=self._u[:1])), np.asarray(cp.get_item_profile(itemID=self._i[:1]))
         if not (np.issubdtype(probe_u.dtype, np.integer) and probe_u.ndim == 1 and np.issubdtype(probe_i.dtype, np.integer) and probe_i.ndim == 1):
             return None  # dense profile rows: built batch by batch
         lookup = cp.device_lookup(device) if device is not None and hasattr(cp, "device_lookup") else None
         if lookup is not None and np.issubdtype(self._u.dtype, np.integer) and np.issubdtype(self._i.dtype, np.integer):
-            return (_to_tensor(self._u), _to_tensor(self._i)), self._targets(), lookup   # raw ids; positions resolved on the GPU
-        return (_to_tensor(cp.get_user_profile(userID=self._u)), _to_tensor(cp.get_item_profile(itemID=self._i))), self._targets(), None
+            return ResidentInputs((_to_tensor(self._u), _to_tensor(self._i)), self._targets(), on_chunk=lookup)  # raw ids; positions resolved on the GPU
+        return ResidentInputs((_to_tensor(cp.get_user_profile(userID=self._u)), _to_tensor(cp.get_item_profile(itemID=self._i))), self._targets())
 
     @staticmethod
     def do_forward(model, batch, device):

@@ -2,7 +2,7 @@
 import numpy as np
 import torch
 
-from .base import PointwiseDataset
+from .base import PointwiseDataset, ResidentInputs
 
 
 class GraphPointwiseDataset(PointwiseDataset):
@@ -16,8 +16,8 @@ class GraphPointwiseDataset(PointwiseDataset):
     def __getitem__(self, item):
         return self._unode[item], self._inode[item], self._r[item]
 
-    def resident_inputs(self, device=None):
-        return (torch.as_tensor(self._unode, dtype=torch.int64), torch.as_tensor(self._inode, dtype=torch.int64)), self._targets(), None
+    def resident_inputs(self, device=None, batch_size=None):
+        return ResidentInputs((torch.as_tensor(self._unode, dtype=torch.int64), torch.as_tensor(self._inode, dtype=torch.int64)), self._targets())
 
     def get_graph(self, device):
         return self.gcp.get_graph().to(device)

@@ -48,10 +48,11 @@ def eval_ranking(samples_with_preds, cutoff=10):
 RESIDENT_CHUNK_BATCHES = 64   # batches uploaded per copy on the side stream
 
 
-def _resident_batches(host_tensors, targets, on_device, batch_size, device):
+def _resident_batches(res, batch_size, device):
     """Yield device-resident batches ``(*inputs[s:e], y[s:e])`` of whole-file host tensors: pinned staging, uploads of
     RESIDENT_CHUNK_BATCHES batches at a time on a side stream, one chunk ahead of the kernels that consume them (the
     compute stream waits on the chunk's event only).  No per-sample Python, no per-batch host-to-device copy."""
+    host_tensors, targets = res.tensors, res.targets
     n = len(targets)
     chunk = max(1, RESIDENT_CHUNK_BATCHES) * batch_size
     side = torch.cuda.Stream(device)
@@ -72,10 +73,11 @@ def _resident_batches(host_tensors, targets, on_device, batch_size, device):
         main.wait_event(ev)
         for t in dev:
             t.record_stream(main)  # allocated on the side stream, consumed on the compute stream
-        if on_device is not None:
-            dev = [*on_device(*dev[:-1]), dev[-1]]  # e.g. raw ids -> table positions, one gather per chunk on the GPU
+        if res.on_chunk is not None:
+            dev = [*res.on_chunk(*dev[:-1]), dev[-1]]  # e.g. raw ids -> table positions, one gather per chunk on the GPU
         for s in range(0, dev[-1].shape[0], batch_size):
-            yield tuple(t[s:s + batch_size] for t in dev)
+            batch = tuple(t[s:s + batch_size] for t in dev)
+            yield batch if res.on_batch is None else res.on_batch(*batch)
 
 
 def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False, device=None, verbose=False, resident=None):
@@ -89,7 +91,7 @@ def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False,
     device = device or next(model.parameters()).device
     model.to(device)
     on_gpu = torch.device(device).type == "cuda"
-    host = test_dataset.resident_inputs(torch.device(device)) if (resident is not False and on_gpu) else None
+    host = test_dataset.resident_inputs(torch.device(device), batch_size) if (resident is not False and on_gpu) else None
     if resident and host is None:
         raise ValueError("resident evaluation needs a CUDA device and a dataset with resident_inputs()")
     graph = test_dataset.get_graph(device)
@@ -100,7 +102,7 @@ def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False,
         if host is not None:
             total_dev = torch.zeros((), dtype=torch.float64, device=device)
             outs = []
-            for batch in _resident_batches(host[0], host[1], host[2], batch_size, torch.device(device)):
+            for batch in _resident_batches(host, batch_size, torch.device(device)):
                 out, y = test_dataset.__class__.do_forward(model, batch, device, *extra)
                 if not ranking:
                     total_dev += test_dataset.calculate_loss(out, y).double()

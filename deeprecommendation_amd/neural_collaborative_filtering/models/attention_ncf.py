@@ -38,9 +38,18 @@ class SparseRatings:
     # grouped vs per-pair: 1 pair per set 335 vs 154 us, 2: 216 vs 153, 4: 128 vs 152, 8: 77 vs 151, 16+: 57 vs 147
     GROUPED_MIN_PAIRS_PER_ROW = 4
 
-    def __init__(self, rowptr, col, val, num_items, pair_row=None):
+    def __init__(self, rowptr, col, val, num_items, pair_row=None, pairs_per_row_hint=None):
         self.rowptr, self.col, self.val, self.num_items = rowptr, col, val, int(num_items)
         self.pair_row = pair_row
+        # average number of pairs per row IN USE, when the CSR holds more rows than the batch touches (a whole user
+        # base kept on the GPU, pair_row = user position): the row count then says nothing about sharing
+        self.pairs_per_row_hint = pairs_per_row_hint
+
+    @property
+    def pairs_per_row(self) -> float:
+        if self.pairs_per_row_hint is not None:
+            return float(self.pairs_per_row_hint)
+        return self.num_pairs / max(1, int(self.rowptr.numel() - 1))
 
     @property
     def num_pairs(self) -> int:
@@ -190,7 +199,7 @@ class AttentionNCF(_ScoringMixin, NCF):
                 mode, w1, b1 = native.ATT_LINEAR, None, 0.0
         shared = ratings.pair_row is not None
         if (shared and native.attn_grouped_supported(mode, pc.shape[1], proj.shape[1])
-                and ratings.num_pairs >= SparseRatings.GROUPED_MIN_PAIRS_PER_ROW * (ratings.rowptr.numel() - 1)):
+                and ratings.pairs_per_row >= SparseRatings.GROUPED_MIN_PAIRS_PER_ROW):
             # several pairs per rated set: stage each set once per workgroup in LDS (K3 grouped form)
             res = native.attn_forward_grouped(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val,
                                               ratings.pair_row, proj, out_bias=lu.bias.detach(),

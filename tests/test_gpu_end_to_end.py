@@ -193,3 +193,39 @@ def test_resident_eval_graph_dataset_and_refusals(gpu):
         eval_model(b2, bad, batch_size=512, device=gpu, resident=False)
     with pytest.raises(IndexError):
         eval_model(b2, bad, batch_size=512, device=gpu, resident=True)
+
+
+@pytest.mark.parametrize("att_dense", [16, None])
+def test_resident_eval_attention_dataset(gpu, att_dense):
+    """DynamicPointwiseDataset through the device-resident loop (whole-catalogue CSR + feature table on the GPU, raw ids
+    uploaded) against the DataLoader loop with the host collate: same scores within 1e-5 (the rated set is the whole
+    catalogue instead of the batch's union: another GEMM shape for the catalogue projections, same sums per user)."""
+    from deeprecommendation_amd.content_providers.index_providers import SparseDynamicProvider
+    from deeprecommendation_amd.neural_collaborative_filtering.datasets.dynamic_datasets import DynamicPointwiseDataset
+    from deeprecommendation_amd.neural_collaborative_filtering.eval import eval_model
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
+    rng = np.random.default_rng(11)
+    I, F, U = 300, 40, 60
+    item_ids = np.arange(1, I + 1) * 3
+    feats = rng.normal(size=(I, F)).astype(np.float32)
+    user_ids = rng.permutation(np.arange(1000, 1000 + U))
+    rated = [np.sort(rng.choice(item_ids, rng.integers(1, 40), replace=False)) for _ in range(U)]
+    ratings = [rng.integers(1, 11, len(r)) * 0.5 for r in rated]
+    means = np.array([r.mean() for r in ratings])
+    prov = SparseDynamicProvider(item_ids, feats, user_ids, rated, ratings, means, sparse=True)
+    n = 3000
+    # samples sorted by user (many pairs per user in a batch -> grouped kernel) and shuffled (-> per-pair kernel)
+    for shuffle in (False, True):
+        u = np.repeat(user_ids, n // U) if not shuffle else rng.choice(user_ids, n)
+        frame = pd.DataFrame({"userId": u, "movieId": rng.choice(item_ids, len(u)), "rating": rng.integers(1, 11, len(u)) * 0.5})
+        ds = DynamicPointwiseDataset(frame, prov)
+        torch.manual_seed(3)
+        m = AttentionNCF(item_dim=F, item_emb=64, user_emb=64, att_dense=att_dense, mlp_dense_layers=[128]).to(gpu)
+        batch = 200 if not shuffle else 30
+        fast = eval_model(m, ds, batch_size=batch, device=gpu, resident=True)
+        slow = eval_model(m, ds, batch_size=batch, device=gpu, resident=False)
+        assert_close(torch.from_numpy(fast["predictions"]).float().view(-1, 1), torch.from_numpy(slow["predictions"]).float().view(-1, 1))
+        assert abs(fast["mse"] - slow["mse"]) <= 1e-5 * slow["mse"]
+    frame.loc[7, "movieId"] = 5  # not a catalogue id
+    with pytest.raises(IndexError):
+        eval_model(m, DynamicPointwiseDataset(frame, prov), batch_size=64, device=gpu, resident=True)

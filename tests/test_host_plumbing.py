@@ -251,21 +251,22 @@ def test_resident_inputs_match_the_dataloader_batches():
     users, items = np.arange(10, 60) * 3, np.arange(1, 30) * 7
     for ds in (FixedPointwiseDataset(frame, IndexProvider(users, items)),
                GraphPointwiseDataset(frame, IndexGraphProvider(users, items, frame["userId"].values, frame["movieId"].values, frame["rating"].values))):
-        (u, i), y, on_device = ds.resident_inputs()
-        assert on_device is None  # no device given: positions resolved on the host
+        res = ds.resident_inputs()
+        (u, i), y = res.tensors, res.targets
+        assert res.on_chunk is None and res.on_batch is None  # no device given: positions resolved on the host
         batches = list(DataLoader(ds, batch_size=50, collate_fn=ds.use_collate()))
         assert torch.equal(u, torch.cat([b[0] for b in batches])) and torch.equal(i, torch.cat([b[1] for b in batches]))
         assert torch.equal(y, torch.cat([b[2] for b in batches])) and u.dtype == torch.int64 and y.dtype == torch.float32
     assert FixedPointwiseDataset(frame, OneHotProvider(users, items)).resident_inputs() is None
     bce = FixedPointwiseDataset(frame, IndexProvider(users, items))
     bce.use_bce_loss = True
-    assert torch.allclose(bce.resident_inputs()[1], torch.as_tensor(frame["rating"].values / 5.0, dtype=torch.float32))
+    assert torch.allclose(bce.resident_inputs().targets, torch.as_tensor(frame["rating"].values / 5.0, dtype=torch.float32))
     # the on-GPU id lookup (run here on the CPU device): raw ids -> the same positions; unknown ids -> -1
     prov = IndexProvider(users, items)
     f = prov.device_lookup(torch.device("cpu"))
     raw = FixedPointwiseDataset(frame, prov).resident_inputs(torch.device("cpu"))
-    assert raw[2] is not None and torch.equal(raw[0][0], torch.as_tensor(frame["userId"].values))
-    up, ip = raw[2](*raw[0])
+    assert raw.on_chunk is not None and torch.equal(raw.tensors[0], torch.as_tensor(frame["userId"].values))
+    up, ip = raw.on_chunk(*raw.tensors)
     assert torch.equal(up, torch.from_numpy(prov.get_user_profile(frame["userId"].values)))
     assert torch.equal(ip, torch.from_numpy(prov.get_item_profile(frame["movieId"].values)))
     up, ip = f(torch.tensor([30, 31, 29, 10 ** 9, -7]), torch.tensor([7, 8, 0, 203, 210]))
@@ -276,3 +277,34 @@ def test_resident_inputs_match_the_dataloader_batches():
     from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
     with pytest.raises(ValueError):
         eval_model(BasicNCF(item_dim=29, user_dim=50, item_emb=8, user_emb=8, mlp_dense_layers=[16]), bce, 32, device="cpu", resident=True)
+
+
+def test_dynamic_provider_device_state_equals_the_collate():
+    """SparseDynamicProvider.device_state (run here on the CPU device): candidate rows and the users' rated sets of a
+    batch assembled from the resident whole-catalogue CSR == collate_interacted_items, column for column on the batch's
+    union of rated items and zero elsewhere; unknown ids raise."""
+    rng = np.random.default_rng(0)
+    I, F, U = 40, 6, 15
+    item_ids = np.arange(100, 100 + I) * 2
+    feats = rng.normal(size=(I, F)).astype(np.float32)
+    user_ids = rng.permutation(np.arange(7, 7 + U))
+    rated = [np.sort(rng.choice(item_ids, rng.integers(1, 9), replace=False)) for _ in range(U)]
+    ratings = [rng.integers(1, 11, len(r)) * 0.5 for r in rated]
+    means = np.array([r.mean() for r in ratings])
+    prov = SparseDynamicProvider(item_ids, feats, user_ids, rated, ratings, means, sparse=True)
+    st = prov.device_state(torch.device("cpu"))
+    assert st is prov.device_state(torch.device("cpu"))  # cached
+    users, cands, tg = rng.choice(user_ids, 20), rng.choice(item_ids, 20), rng.random(20)
+    _, rated_ids, candidate_items, _, um, _ = prov.collate_interacted_items(list(zip(users.tolist(), cands.tolist(), tg.tolist())), for_ranking=False)
+    got = st.batch(torch.as_tensor(users), torch.as_tensor(cands), torch.as_tensor(tg), pairs_per_row_hint=2.5)
+    assert torch.equal(got[2], candidate_items) and got[3] is st.features and got[4].pairs_per_row == 2.5
+    local, whole = um.to_dense(um.val), got[4].to_dense(got[4].val)
+    colpos = np.searchsorted(prov.item_ids, rated_ids)
+    assert torch.equal(whole[:, colpos], local)
+    rest = np.ones(I, bool)
+    rest[colpos] = False
+    assert float(whole[:, rest].abs().sum()) == 0.0
+    with pytest.raises(KeyError):
+        st.batch(torch.tensor([9999]), torch.tensor([200]), torch.tensor([0.0]))
+    sparse_ids = SparseDynamicProvider(np.array([1, 10 ** 9]), feats[:2], user_ids, [np.array([1])] * U, [np.array([3.0])] * U, means)
+    assert sparse_ids.device_state(torch.device("cpu")) is None
