@@ -45,6 +45,59 @@ def eval_ranking(samples_with_preds, cutoff=10):
     return float(np.mean(ndcg)), float(np.mean(adj))
 
 
+def _dcg_orders(uidx, y_score):
+    """Rows ordered by user, then by descending score (ties in input order) — the np.lexsort of _dcg_per_user as two
+    stable device sorts; independent of the cut-off, so one ordering serves every k."""
+    by_score = torch.argsort(y_score, descending=True, stable=True)
+    return by_score[torch.argsort(uidx[by_score], stable=True)]
+
+
+def _dcg_per_user_torch(order, uidx, n_users, y_true, y_score, cutoffs):
+    """_dcg_per_user on tensors (any device, float64), for several cut-offs from one ordering."""
+    u, t, sc = uidx[order], y_true[order], y_score[order]
+    n = u.numel()
+    idx = torch.arange(n, device=u.device)
+    first = torch.ones(n, dtype=torch.bool, device=u.device)
+    first[1:] = u[1:] != u[:-1]
+    rank = idx - torch.cummax(torch.where(first, idx, torch.zeros_like(idx)), 0).values   # 0-based rank inside the user
+    new_group = first.clone()
+    new_group[1:] |= sc[1:] != sc[:-1]
+    gid = torch.cumsum(new_group, 0) - 1
+    n_groups = int(gid[-1].item()) + 1 if n else 0
+    cnt = torch.bincount(gid, minlength=n_groups).to(torch.float64)
+    gain = torch.bincount(gid, weights=t, minlength=n_groups) / cnt     # mean gain of each tie group
+    owner = u[new_group]
+    out = []
+    for k in cutoffs:
+        disc = torch.where(rank < k, 1.0 / torch.log2(rank.to(torch.float64) + 2.0), torch.zeros((), dtype=torch.float64, device=u.device))
+        dsum = torch.bincount(gid, weights=disc, minlength=n_groups)    # discounts the group's positions collect
+        out.append(torch.bincount(owner, weights=gain * dsum, minlength=n_users))
+    return out
+
+
+def eval_ranking_device(users, rating, pred, cutoffs=(5, 10, 20), device=None):
+    """eval_ranking for several cut-offs with the sorts and segment sums on ``device`` (three stable sort pairs in all,
+    instead of nine host lexsorts): ``{k: (mean NDCG, mean adjusted NDCG)}``.  Same definition and tie handling as
+    eval_ranking; float64 throughout (bincount's atomic adds make the last bits run-dependent)."""
+    device = torch.device(device) if device is not None else (pred.device if torch.is_tensor(pred) else torch.device("cpu"))
+    as_t = lambda x, dt: (x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))).to(device=device, dtype=dt).reshape(-1)
+    users, rating, pred = as_t(users, torch.int64), as_t(rating, torch.float64), as_t(pred, torch.float64)
+    if users.numel() == 0:
+        return {k: (float("nan"), float("nan")) for k in cutoffs}
+    _, uidx, counts = torch.unique(users, return_inverse=True, return_counts=True)
+    n = counts.numel()
+    dcg = _dcg_per_user_torch(_dcg_orders(uidx, pred), uidx, n, rating, pred, cutoffs)
+    ideal = _dcg_per_user_torch(_dcg_orders(uidx, rating), uidx, n, rating, rating, cutoffs)
+    worst = _dcg_per_user_torch(_dcg_orders(uidx, 5.0 - rating), uidx, n, rating, 5.0 - rating, cutoffs)
+    res = {}
+    for j, k in enumerate(cutoffs):
+        keep = (counts > 1) & (ideal[j] != worst[j])
+        d, i, w = dcg[j][keep], ideal[j][keep], worst[j][keep]
+        ndcg = torch.where(i != 0, d / torch.where(i != 0, i, torch.ones_like(i)), torch.zeros_like(i))
+        res[k] = (float(ndcg.mean().item()), float(((d - w) / (i - w)).mean().item())) if d.numel() else (float("nan"), float("nan"))
+    return res
+
+
 RESIDENT_CHUNK_BATCHES = 64   # batches uploaded per copy on the side stream
 
 
@@ -97,7 +150,7 @@ def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False,
     graph = test_dataset.get_graph(device)
     extra = [] if graph is None else [graph]
     model.eval()
-    fitted, total = [], 0.0
+    fitted, total, pred_dev = [], 0.0, None
     with torch.no_grad():
         if host is not None:
             total_dev = torch.zeros((), dtype=torch.float64, device=device)
@@ -108,7 +161,8 @@ def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False,
                     total_dev += test_dataset.calculate_loss(out, y).double()
                 outs.append(out)
             total = float(total_dev.item())
-            fitted = [torch.cat(outs).cpu().numpy()] if outs else [np.zeros((0, 1), dtype=np.float32)]
+            pred_dev = torch.cat(outs).reshape(-1) if outs else None
+            fitted = [pred_dev.cpu().numpy()] if outs else [np.zeros((0, 1), dtype=np.float32)]
         else:
             loader = DataLoader(test_dataset, batch_size=batch_size, collate_fn=test_dataset.use_collate())  # sequential order
             for batch in loader:
@@ -124,9 +178,16 @@ def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False,
     if not ranking:
         res["mse"] = total / len(test_dataset)
         res["rmse"] = sqrt(res["mse"])
-    frame = test_dataset.samples.assign(prediction=pred)
+    ranked = None
+    if np.issubdtype(test_dataset.samples['userId'].to_numpy().dtype, np.integer):
+        # sorts and segment sums of the ranking metrics on the model's device (nine host lexsorts cost 4.4 s per million
+        # samples; three device sort pairs serve all three cut-offs)
+        ranked = eval_ranking_device(test_dataset.samples['userId'].to_numpy(), test_dataset.samples['rating'].to_numpy(dtype=np.float64),
+                                     pred_dev if pred_dev is not None else pred, (5, 10, 20), device)
+    else:
+        frame = test_dataset.samples.assign(prediction=pred)
     for k in (5, 10, 20):
-        res[f"ndcg@{k}"], res[f"adj_ndcg@{k}"] = eval_ranking(frame, cutoff=k)
+        res[f"ndcg@{k}"], res[f"adj_ndcg@{k}"] = ranked[k] if ranked is not None else eval_ranking(frame, cutoff=k)
     if verbose:
         print({k: v for k, v in res.items() if k != "predictions"})
     return res

@@ -308,3 +308,21 @@ def test_dynamic_provider_device_state_equals_the_collate():
         st.batch(torch.tensor([9999]), torch.tensor([200]), torch.tensor([0.0]))
     sparse_ids = SparseDynamicProvider(np.array([1, 10 ** 9]), feats[:2], user_ids, [np.array([1])] * U, [np.array([3.0])] * U, means)
     assert sparse_ids.device_state(torch.device("cpu")) is None
+
+
+@pytest.mark.parametrize("n,n_users", [(2000, 100), (30000, 2000), (7, 7), (300, 1), (0, 1)])
+def test_eval_ranking_device_equals_eval_ranking(n, n_users):
+    """The tensor implementation of the ranking metrics (run here on the CPU device; eval_model runs it on the GPU)
+    against the numpy one that is pinned to the reference's NDCG goldens: heavy score ties, single-row users, users whose
+    ideal and worst DCG coincide, all three cut-offs from one ordering."""
+    rng = np.random.default_rng(n + n_users)
+    users = rng.integers(0, n_users, n) * 7 + 3
+    rating = rng.integers(1, 11, n) * 0.5
+    pred = np.round(rng.normal(3, 1, n), 1).astype(np.float32).astype(np.float64)
+    got = E.eval_ranking_device(users, rating, pred, (5, 10, 20))
+    if n == 0:
+        assert all(np.isnan(v[0]) for v in got.values())
+        return
+    frame = pd.DataFrame({"userId": users, "rating": rating, "prediction": pred})
+    for k in (5, 10, 20):
+        assert np.allclose(got[k], E.eval_ranking(frame, cutoff=k), rtol=1e-12, atol=1e-12, equal_nan=True)

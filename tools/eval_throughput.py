@@ -35,9 +35,11 @@ def main():
 
     # metrics (NDCG over all users) are host-side numpy and identical for both loops: time the scoring loop alone
     # (ranking=True skips nothing of the forward; the loss is timed separately below)
-    def run(ds, resident, with_loss):
-        orig = E.eval_ranking
-        E.eval_ranking = lambda *a, **k: (0.0, 0.0)
+    def run(ds, resident, with_loss, metrics=False):
+        orig = E.eval_ranking, E.eval_ranking_device
+        if not metrics:
+            E.eval_ranking = lambda *a, **k: (0.0, 0.0)
+            E.eval_ranking_device = lambda *a, **k: {5: (0.0, 0.0), 10: (0.0, 0.0), 20: (0.0, 0.0)}
         try:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -45,7 +47,7 @@ def main():
             torch.cuda.synchronize()
             return time.perf_counter() - t0, res
         finally:
-            E.eval_ranking = orig
+            E.eval_ranking, E.eval_ranking_device = orig
 
     small = dataset(n_slow)
     run(small, True, True)  # warm-up: tables, packed weights, clocks
@@ -63,6 +65,16 @@ def main():
         tf, _ = run(big, True, with_loss)
         print(f"{n_fast} samples, loss={with_loss}: resident loop {tf * 1e3:.1f} ms = {n_fast / tf / 1e6:.1f} M pairs/s "
               f"(of which host-side input preparation {t_prep * 1e3:.0f} ms)", flush=True)
+    tm, res = run(big, True, True, metrics=True)
+    print(f"{n_fast} samples, loss + NDCG / adjusted NDCG @5/10/20 on the GPU: {tm * 1e3:.1f} ms = {n_fast / tm / 1e6:.1f} M pairs/s "
+          f"(ndcg@10 {res['ndcg@10']:.4f})", flush=True)
+    import pandas as pd2  # the host implementation on a slice, for scale
+    part = 1_000_000
+    frame = big.samples.iloc[:part].assign(prediction=res["predictions"][:part])
+    t0 = time.perf_counter()
+    for k in (5, 10, 20):
+        E.eval_ranking(frame, cutoff=k)
+    print(f"host numpy ranking metrics on {part} samples: {time.perf_counter() - t0:.2f} s", flush=True)
 
 
 if __name__ == "__main__":
