@@ -133,8 +133,10 @@ def _resident_batches(res, batch_size, device):
             yield batch if res.on_batch is None else res.on_batch(*batch)
 
 
-def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False, device=None, verbose=False, resident=None):
-    """eval.py:78-182 (metrics only).  Returns a dict: predictions, mse, rmse, ndcg@k / adj_ndcg@k for k = 5, 10, 20.
+def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False, device=None, verbose=False, resident=None,
+               cutoffs=(5, 10, 20)):
+    """eval.py:78-182 (metrics only).  Returns a dict: predictions, mse, rmse, ndcg@k / adj_ndcg@k for k in ``cutoffs``
+    (the reference reports 5, 10, 20).
 
     ``resident`` (None = when possible): datasets whose inputs are index ids (`Dataset.resident_inputs`) are evaluated
     without the DataLoader — same batches, same ``do_forward`` plug-in call, same per-batch loss sums accumulated in
@@ -183,10 +185,10 @@ def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False,
         # sorts and segment sums of the ranking metrics on the model's device (nine host lexsorts cost 4.4 s per million
         # samples; three device sort pairs serve all three cut-offs)
         ranked = eval_ranking_device(test_dataset.samples['userId'].to_numpy(), test_dataset.samples['rating'].to_numpy(dtype=np.float64),
-                                     pred_dev if pred_dev is not None else pred, (5, 10, 20), device)
+                                     pred_dev if pred_dev is not None else pred, tuple(cutoffs), device)
     else:
         frame = test_dataset.samples.assign(prediction=pred)
-    for k in (5, 10, 20):
+    for k in cutoffs:
         res[f"ndcg@{k}"], res[f"adj_ndcg@{k}"] = ranked[k] if ranked is not None else eval_ranking(frame, cutoff=k)
     if verbose:
         print({k: v for k, v in res.items() if k != "predictions"})

@@ -2,6 +2,8 @@
 against the same model run with plain torch ops on the CPU (the reference's training arithmetic)."""
 import copy
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -191,3 +193,66 @@ def test_training_steps_with_fused_adam_track_torch(gpu):
     for a, b in zip(losses["hip"], losses["torch"]):
         assert abs(a - b) <= 1e-5 * abs(b)
     assert losses["hip"][-1] < losses["hip"][0]
+
+
+def _toy_files(n=6000, U=300, I=120, seed=0):
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    u, i = rng.integers(1, U + 1, n), rng.integers(1, I + 1, n)
+    r = np.clip(np.round(((u % 5) + (i % 3)) * 0.5 + 1 + rng.normal(0, 0.2, n), 1), 0.5, 5.0)
+    frame = pd.DataFrame({"userId": u, "movieId": i, "rating": r})
+    cut = n * 4 // 5
+    return frame.iloc[:cut].reset_index(drop=True), frame.iloc[cut:].reset_index(drop=True), U, I
+
+
+def test_train_model_resident_loop_equals_dataloader_loop(gpu, tmp_path):
+    """train_model (reference train.py:21-227 signature): with shuffling off, the device-resident epoch (ids uploaded once,
+    batches gathered on the GPU, loss kept on the device) and the DataLoader epoch see the same batches -> the same
+    training / validation curves; FusedAdam vs torch Adam and HIP autograd blocks on both sides."""
+    from deeprecommendation_amd.content_providers.index_providers import IndexProvider
+    from deeprecommendation_amd.neural_collaborative_filtering.datasets.fixed_datasets import FixedPointwiseDataset
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    from deeprecommendation_amd.neural_collaborative_filtering.train import train_model
+    tr, va, U, I = _toy_files()
+    prov = IndexProvider(np.arange(1, U + 1), np.arange(1, I + 1))
+    curves = {}
+    for resident in (True, False):
+        torch.manual_seed(0)
+        m = BasicNCF(item_dim=I, user_dim=U, item_emb=64, user_emb=64, mlp_dense_layers=[256, 128], dropout_rate=0.0)
+        curves[resident] = train_model(m, FixedPointwiseDataset(tr, prov), FixedPointwiseDataset(va, prov), lr=2e-3, weight_decay=1e-5,
+                                       batch_size=512, val_batch_size=1024, early_stop=True, final_model_path=str(tmp_path / "f.pt"),
+                                       checkpoint_model_path=str(tmp_path / "c.pt"), max_epochs=4, device=gpu, resident=resident,
+                                       shuffle=False, verbose=False)
+    a, b = curves[True], curves[False]
+    assert len(a["train_loss"]) == len(b["train_loss"]) >= 2
+    np.testing.assert_allclose(a["train_loss"], b["train_loss"], rtol=2e-4)
+    np.testing.assert_allclose(a["val_loss"], b["val_loss"], rtol=2e-4)
+    assert a["train_loss"][-1] < a["train_loss"][0]
+
+
+def test_train_model_learns_restores_best_checkpoint_and_saves(gpu, tmp_path):
+    """Shuffled resident epochs with dropout: the loss falls; early stopping restores the best epoch's weights (the final
+    file holds the checkpoint's state, as train.py:196-199 + :222 leave it) and the checkpoint format loads back."""
+    from deeprecommendation_amd.content_providers.index_providers import IndexProvider
+    from deeprecommendation_amd.neural_collaborative_filtering.datasets.fixed_datasets import FixedPointwiseDataset
+    from deeprecommendation_amd.neural_collaborative_filtering.eval import eval_model
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    from deeprecommendation_amd.neural_collaborative_filtering.train import train_model
+    from deeprecommendation_amd.neural_collaborative_filtering.util import load_model
+    tr, va, U, I = _toy_files(seed=1)
+    prov = IndexProvider(np.arange(1, U + 1), np.arange(1, I + 1))
+    torch.manual_seed(1)
+    m = BasicNCF(item_dim=I, user_dim=U, item_emb=64, user_emb=64, mlp_dense_layers=[256, 128], dropout_rate=0.2)
+    vds = FixedPointwiseDataset(va, prov)
+    # lr large enough to overfit / oscillate within a few epochs, patience 0: stops early
+    mm = train_model(m, FixedPointwiseDataset(tr, prov), vds, lr=2e-2, weight_decay=0.0, batch_size=256, val_batch_size=1024,
+                     early_stop=True, final_model_path=str(tmp_path / "final.pt"), checkpoint_model_path=str(tmp_path / "ckpt.pt"),
+                     max_epochs=25, patience=0, max_patience=3, device=gpu, verbose=False)
+    assert min(mm["train_loss"]) < mm["train_loss"][0]
+    assert len(mm["val_loss"]) == len(mm["train_loss"]) == len(mm["val_ndcg"]) <= 25
+    best = int(np.argmin(mm["val_loss"]))
+    reloaded = load_model(str(tmp_path / "final.pt"), BasicNCF).to(gpu)
+    res = eval_model(reloaded, vds, 1024, device=gpu)
+    assert abs(res["mse"] - mm["val_loss"][best]) <= 1e-4 * mm["val_loss"][best]
+    with pytest.raises(NotImplementedError):
+        train_model(m, object(), vds, 1e-3, 0, 8, 8, False, device=gpu)

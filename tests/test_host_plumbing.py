@@ -326,3 +326,30 @@ def test_eval_ranking_device_equals_eval_ranking(n, n_users):
     frame = pd.DataFrame({"userId": users, "rating": rating, "prediction": pred})
     for k in (5, 10, 20):
         assert np.allclose(got[k], E.eval_ranking(frame, cutoff=k), rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
+def test_early_stopping_follows_the_reference_rule():
+    """EarlyStopping against a literal replay of train.py:157-210's counters (point-wise branch) on random loss curves."""
+    from deeprecommendation_amd.neural_collaborative_filtering.train import EarlyStopping
+    rng = np.random.default_rng(4)
+    for trial in range(200):
+        patience, max_patience = int(rng.integers(0, 4)), int(rng.integers(1, 7))
+        losses = np.round(rng.random(30) + np.linspace(1, 0.5, 30) * rng.random(), 2)   # rounding: exact ties occur
+        es = EarlyStopping(patience, max_patience)
+        times, best, prev, budget = 0, None, None, max_patience
+        for epoch, v in enumerate(losses):
+            if best is None or v < best:
+                best, times, budget, want = v, 0, max_patience, "best"
+            else:
+                if prev is not None and v > prev:
+                    times += 1
+                else:
+                    times = max(0, times - 1)
+                budget -= 1
+                want = "stop" if (times > patience or budget <= 0) else "continue"
+            prev = v
+            got = es.update(float(v), epoch)
+            assert got == want, (trial, epoch)
+            assert es.best == best and es.strikes == times
+            if want == "stop":
+                break
