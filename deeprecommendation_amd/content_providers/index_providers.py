@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from ..neural_collaborative_filtering.content_providers import ContentProvider, DynamicContentProvider, GraphContentProvider
-from ..neural_collaborative_filtering.models.attention_ncf import SparseRatings
+from ..neural_collaborative_filtering.models.attention_ncf import RowsOf, SparseRatings
 from ..neural_collaborative_filtering.models.gnn_ncf import GraphData
 
 
@@ -307,9 +307,9 @@ class _DynamicDeviceState:
 
     def batch_at(self, upos, cpos, y, pairs_per_row_hint=None):
         """The collate's 6-tuple for one batch of positions (cand_ids carries catalogue positions, rated_ids is None: the
-        rated list is the whole catalogue in provider order)."""
+        rated list is the whole catalogue in provider order; the candidate rows stay an unevaluated selection of it)."""
         ratings = SparseRatings(self.rowptr, self.col, self.val, self.num_items, pair_row=upos, pairs_per_row_hint=pairs_per_row_hint)
-        return cpos, None, self.features.index_select(0, cpos), self.features, ratings, y
+        return cpos, None, RowsOf(self.features, cpos), self.features, ratings, y
 
     def batch(self, users, cands, y, pairs_per_row_hint=None):
         return self.batch_at(*self.positions(users, cands), y, pairs_per_row_hint)

@@ -25,6 +25,37 @@ from .base import NCF
 from .basic_ncf import _ScoringMixin
 
 
+class RowsOf:
+    """``table[index]`` left unevaluated: a (B, F) candidate batch that is a selection of rows of a resident feature
+    table.  When the table is the very tensor passed as ``rated_items`` the model takes the candidates' embeddings from the
+    catalogue embeddings it has already computed (``rated_emb[index]``: a 1 MB gather) instead of gathering B × F
+    features and running the F -> IE Linear again (34 MB + 1.1 GFLOP per 4096-pair batch at config 3)."""
+
+    def __init__(self, table: torch.Tensor, index: torch.Tensor):
+        self.table, self.index = table, index
+
+    @property
+    def is_cuda(self):
+        return self.table.is_cuda and self.index.is_cuda
+
+    @property
+    def device(self):
+        return self.table.device
+
+    @property
+    def shape(self):
+        return (self.index.shape[0], self.table.shape[1])
+
+    def float(self):
+        return self if self.table.dtype == torch.float32 else RowsOf(self.table.float(), self.index)
+
+    def to(self, device):
+        return self if self.table.device == torch.device(device) and self.index.device == torch.device(device) else RowsOf(self.table.to(device), self.index.to(device))
+
+    def materialise(self) -> torch.Tensor:
+        return self.table.index_select(0, self.index)
+
+
 class SparseRatings:
     """CSR form of the (B, I) ``user_matrix``: row b owns entries [rowptr[b], rowptr[b+1]) with ``col`` = position in
     the rated-item list and ``val`` = the non-zero normalised rating.  Providers can emit this directly instead of
@@ -177,12 +208,20 @@ class AttentionNCF(_ScoringMixin, NCF):
 
     def forward(self, candidate_items, rated_items, user_matrix, return_attention_weights=False):
         if not use_native(self):
+            if isinstance(candidate_items, RowsOf):
+                candidate_items = candidate_items.materialise()
             return self._forward_train(candidate_items, rated_items, user_matrix, return_attention_weights)
         require_gpu(candidate_items, rated_items)
         cache = self._refresh()  # ONE parameter fingerprint per forward (it walks the module tree: ~12 us of host time)
         li, lu = self.ItemEmbeddings[0], self.UserEmbeddings[0]
-        cand_emb = native.linear(candidate_items.float().contiguous(), li.weight.detach(), li.bias.detach())
         rated_emb, pr, proj = self.precompute_catalog(rated_items, cache)
+        if isinstance(candidate_items, RowsOf):
+            if candidate_items.table is rated_items:
+                cand_emb = rated_emb.index_select(0, candidate_items.index)   # same Linear, already applied to every row
+            else:
+                cand_emb = native.linear(candidate_items.materialise().float().contiguous(), li.weight.detach(), li.bias.detach())
+        else:
+            cand_emb = native.linear(candidate_items.float().contiguous(), li.weight.detach(), li.bias.detach())
         ratings = user_matrix if isinstance(user_matrix, SparseRatings) else SparseRatings.from_dense(user_matrix)
         if self.use_cos_sim_instead:
             mode, pc, w1, b1 = native.ATT_COS, native.l2_normalize_rows(cand_emb), None, 0.0

@@ -297,7 +297,8 @@ def test_dynamic_provider_device_state_equals_the_collate():
     users, cands, tg = rng.choice(user_ids, 20), rng.choice(item_ids, 20), rng.random(20)
     _, rated_ids, candidate_items, _, um, _ = prov.collate_interacted_items(list(zip(users.tolist(), cands.tolist(), tg.tolist())), for_ranking=False)
     got = st.batch(torch.as_tensor(users), torch.as_tensor(cands), torch.as_tensor(tg), pairs_per_row_hint=2.5)
-    assert torch.equal(got[2], candidate_items) and got[3] is st.features and got[4].pairs_per_row == 2.5
+    assert torch.equal(got[2].materialise(), candidate_items) and got[2].table is got[3] is st.features and got[4].pairs_per_row == 2.5
+    assert got[2].float().to(torch.device("cpu")) is got[2] and got[2].shape == candidate_items.shape
     local, whole = um.to_dense(um.val), got[4].to_dense(got[4].val)
     colpos = np.searchsorted(prov.item_ids, rated_ids)
     assert torch.equal(whole[:, colpos], local)
