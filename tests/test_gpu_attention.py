@@ -287,3 +287,32 @@ def test_attention_grouped_large_batch_matches_per_pair(native, gpu):
     out_p, _ = native.attn_forward(native.ATT_MLP, pc, pr, w1, -0.1, ex.rowptr, ex.col, ex.val, feat)
     assert_close(out_g, out_p)
     native.check_oob(gpu)
+
+
+@pytest.mark.parametrize("cos", [False, True])
+def test_candidates_as_rows_of_the_catalogue(native, gpu, cos):
+    """AttentionNCF.forward with the candidates given as RowsOf(rated_items, index) (embeddings taken from the catalogue
+    pass) == the same forward on the materialised feature rows; a RowsOf over ANOTHER table is materialised first."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF, RowsOf, SparseRatings
+    from test_gpu_basic import assert_close
+    g = torch.Generator().manual_seed(5)
+    I, F, B, R = 500, 48, 300, 12
+    feats = torch.randn(I, F, generator=g).to(gpu)
+    torch.manual_seed(7)
+    m = AttentionNCF(item_dim=F, item_emb=64, user_emb=64, att_dense=None if cos else 32, mlp_dense_layers=[128],
+                     use_cos_sim_instead=cos).to(gpu).eval()
+    counts = torch.randint(1, 40, (R,), generator=g)
+    rowptr = torch.zeros(R + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    col = torch.cat([torch.randperm(I, generator=g)[:c].sort().values for c in counts.tolist()]).to(torch.int32)
+    val = torch.randn(int(rowptr[-1]), generator=g).abs() + 0.1
+    pair_row = torch.randint(0, R, (B,), generator=g)
+    cand = torch.randint(0, I, (B,), generator=g).to(gpu)
+    ratings = SparseRatings(rowptr.to(gpu), col.to(gpu), val.to(gpu), I, pair_row=pair_row.to(gpu))
+    with torch.no_grad():
+        dense = m(feats[cand], feats, ratings)
+        lazy = m(RowsOf(feats, cand), feats, ratings)
+        other = m(RowsOf(feats.clone(), cand), feats, ratings)
+    assert_close(lazy, dense)
+    assert_close(other, dense)
+    assert lazy.shape == (B, 1)

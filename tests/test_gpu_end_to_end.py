@@ -152,7 +152,8 @@ def test_resident_eval_equals_dataloader_eval(gpu, monkeypatch, n, batch):
     assert np.array_equal(fast["predictions"], slow["predictions"])
     assert abs(fast["mse"] - slow["mse"]) <= 1e-12 * slow["mse"]
     for k in (5, 10, 20):
-        assert np.isclose(fast[f"ndcg@{k}"], slow[f"ndcg@{k}"], rtol=0, atol=0, equal_nan=True)  # nan: no user with 2+ rows
+        # same predictions -> same metric up to the order of the float64 atomic adds of the device bincount; nan: no user with 2+ rows
+        assert np.isclose(fast[f"ndcg@{k}"], slow[f"ndcg@{k}"], rtol=1e-12, atol=0, equal_nan=True)
 
 
 def test_resident_eval_graph_dataset_and_refusals(gpu):
