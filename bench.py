@@ -175,6 +175,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "train2"],
                     help="cfg2 = BASELINE headline (default); cfg3 / cfg4 = the other single-GPU configs (bench_extra.py)")
     args = ap.parse_args()
+    # torch sizes its OpenMP pool from the visible CPUs (256 on the GPU box, of which the cgroup grants 16): surplus workers
+    # spinning after a host-side parallel region get the enqueueing thread throttled — keep the pool within the share
+    torch.set_num_threads(min(torch.get_num_threads(), host_cores()))
     if args.workload != "cfg2":
         import bench_extra
         return bench_extra.main(args)

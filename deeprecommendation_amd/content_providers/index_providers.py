@@ -301,14 +301,34 @@ class _DynamicDeviceState:
             raise KeyError(f"unknown id(s): {ids[bad][:5].tolist()}")
         return pos.clamp_min(0)
 
-    def positions(self, users, cands):
-        """Raw id tensors -> (user position, catalogue position); done once per uploaded CHUNK of batches."""
-        return self._lookup(users, self.user_lo, self.user_table), self._lookup(cands, self.item_lo, self.item_table)
+    COMPACT_MIN_USERS = 4096   # user bases above this get a chunk-local CSR (the grouping pass is O(rows of the CSR))
 
-    def batch_at(self, upos, cpos, y, pairs_per_row_hint=None):
-        """The collate's 6-tuple for one batch of positions (cand_ids carries catalogue positions, rated_ids is None: the
-        rated list is the whole catalogue in provider order; the candidate rows stay an unevaluated selection of it)."""
-        ratings = SparseRatings(self.rowptr, self.col, self.val, self.num_items, pair_row=upos, pairs_per_row_hint=pairs_per_row_hint)
+    def positions(self, users, cands):
+        """Raw id tensors -> (CSR row of each sample, catalogue position); done once per uploaded CHUNK of batches.
+
+        With a large user base the chunk's distinct users are compacted into a chunk-local CSR (two size read-backs per
+        chunk, none per batch): the pair-grouping pass and the grouped kernel's grid bound scale with the rows of the CSR
+        they are handed, and a batch touches a few dozen of possibly millions of users."""
+        upos, cpos = self._lookup(users, self.user_lo, self.user_table), self._lookup(cands, self.item_lo, self.item_table)
+        if self.rowptr.numel() - 1 <= self.COMPACT_MIN_USERS:
+            self._chunk_csr = (self.rowptr, self.col, self.val)
+            return upos, cpos
+        uniq, local_row = torch.unique(upos, return_inverse=True)
+        start = self.rowptr[:-1][uniq]
+        counts = self.rowptr[1:][uniq] - start
+        rowptr = torch.zeros(uniq.numel() + 1, dtype=torch.int64, device=upos.device)
+        rowptr[1:] = torch.cumsum(counts, 0)
+        owner = torch.repeat_interleave(torch.arange(uniq.numel(), device=upos.device), counts)
+        src = start[owner] + (torch.arange(owner.numel(), device=upos.device) - rowptr[:-1][owner])
+        self._chunk_csr = (rowptr, self.col[src], self.val[src])
+        return local_row, cpos
+
+    def batch_at(self, rows, cpos, y, pairs_per_row_hint=None):
+        """The collate's 6-tuple for one batch of the chunk last passed to ``positions`` (cand_ids carries catalogue
+        positions, rated_ids is None: the rated list is the whole catalogue in provider order; the candidate rows stay an
+        unevaluated selection of it)."""
+        rowptr, col, val = self._chunk_csr
+        ratings = SparseRatings(rowptr, col, val, self.num_items, pair_row=rows, pairs_per_row_hint=pairs_per_row_hint)
         return cpos, None, RowsOf(self.features, cpos), self.features, ratings, y
 
     def batch(self, users, cands, y, pairs_per_row_hint=None):

@@ -17,7 +17,7 @@ from torch.utils.data import DataLoader
 
 from .datasets.base import PointwiseDataset
 from .eval import eval_model
-from .util import load_model
+from .util import cap_host_threads, load_model
 
 
 class EarlyStopping:
@@ -70,6 +70,7 @@ def train_model(model, train_dataset, val_dataset: PointwiseDataset, lr, weight_
     if not isinstance(train_dataset, PointwiseDataset) or not isinstance(val_dataset, PointwiseDataset):
         raise NotImplementedError("only point-wise training is mirrored (pair-wise BPR training stays with the reference loop)")
     device = torch.device(device) if device is not None else torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+    cap_host_threads()
     model.to(device)
     if not model.is_dataset_compatible(train_dataset.__class__) or not model.is_dataset_compatible(val_dataset.__class__):
         raise Exception('Model used is incompatible with this dataset.')

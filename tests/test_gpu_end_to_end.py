@@ -196,15 +196,19 @@ def test_resident_eval_graph_dataset_and_refusals(gpu):
         eval_model(b2, bad, batch_size=512, device=gpu, resident=True)
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("att_dense", [16, None])
-def test_resident_eval_attention_dataset(gpu, att_dense):
+def test_resident_eval_attention_dataset(gpu, monkeypatch, att_dense, compact):
     """DynamicPointwiseDataset through the device-resident loop (whole-catalogue CSR + feature table on the GPU, raw ids
     uploaded) against the DataLoader loop with the host collate: same scores within 1e-5 (the rated set is the whole
     catalogue instead of the batch's union: another GEMM shape for the catalogue projections, same sums per user)."""
+    from deeprecommendation_amd.content_providers import index_providers
     from deeprecommendation_amd.content_providers.index_providers import SparseDynamicProvider
     from deeprecommendation_amd.neural_collaborative_filtering.datasets.dynamic_datasets import DynamicPointwiseDataset
     from deeprecommendation_amd.neural_collaborative_filtering.eval import eval_model
     from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
+    if compact:   # the path user bases above 4096 take: chunk-local CSR of the chunk's distinct users
+        monkeypatch.setattr(index_providers._DynamicDeviceState, "COMPACT_MIN_USERS", 0)
     rng = np.random.default_rng(11)
     I, F, U = 300, 40, 60
     item_ids = np.arange(1, I + 1) * 3

@@ -305,6 +305,12 @@ def test_dynamic_provider_device_state_equals_the_collate():
     rest = np.ones(I, bool)
     rest[colpos] = False
     assert float(whole[:, rest].abs().sum()) == 0.0
+    # large user bases: the chunk's distinct users are compacted into a chunk-local CSR; same dense matrix
+    st.COMPACT_MIN_USERS = 0
+    compact = st.batch(torch.as_tensor(users), torch.as_tensor(cands), torch.as_tensor(tg))
+    assert compact[4].rowptr.numel() - 1 == len(np.unique(users)) < U
+    assert torch.equal(compact[4].to_dense(compact[4].val), whole)
+    del st.COMPACT_MIN_USERS
     with pytest.raises(KeyError):
         st.batch(torch.tensor([9999]), torch.tensor([200]), torch.tensor([0.0]))
     sparse_ids = SparseDynamicProvider(np.array([1, 10 ** 9]), feats[:2], user_ids, [np.array([1])] * U, [np.array([3.0])] * U, means)

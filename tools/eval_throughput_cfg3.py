@@ -52,6 +52,10 @@ def main():
         finally:
             E.eval_ranking = orig
 
+    if os.environ.get("EVAL_GC_FREEZE"):
+        import gc
+        gc.collect()
+        gc.freeze()   # experiment: are the host-side stalls of the loop cyclic-GC passes over the provider's objects?
     small = dataset(user_ids[:loader_batches * (B // PER_USER)])
     t0 = time.perf_counter()
     prov.device_state(dev)
