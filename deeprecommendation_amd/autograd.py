@@ -74,6 +74,46 @@ class GatherColumnsFn(torch.autograd.Function):
         return dW, db, None
 
 
+class GatherColumnsConcatFn(torch.autograd.Function):
+    """cat(W_a[:, idx_a] + b_a, W_b[:, idx_b] + b_b) for two id-major embedding parameters in ONE gather into the (B, Ea+Eb)
+    activation (``basic_ncf.py:37-40``: both embedding Linears, then the concat).  Against two GatherColumnsFn + torch.cat
+    it saves the concat copy forward and, backward, the two column-slice copies and one of the two bias reductions: the
+    gradient rows are scattered straight from the column halves of dX (the scatter kernel takes a row stride).  Both
+    weights must be id-major (util.row_major_embedding_); the caller falls back to GatherColumnsFn + cat otherwise."""
+
+    @staticmethod
+    def forward(ctx, wa, ba, idx_a, wb, bb, idx_b):
+        ctx.save_for_backward(idx_a, idx_b)
+        ctx.shapes = (tuple(wa.shape), tuple(wb.shape))
+        ctx.has_bias = (ba is not None, bb is not None)
+        x = native.gather_concat(wa.t(), idx_a, wb.t(), idx_b)
+        if ba is not None or bb is not None:
+            ea, eb = wa.shape[0], wb.shape[0]
+            bias = torch.cat((ba if ba is not None else x.new_zeros(ea), bb if bb is not None else x.new_zeros(eb)))
+            x.add_(bias)
+        return x
+
+    @staticmethod
+    def backward(ctx, dX):
+        idx_a, idx_b = ctx.saved_tensors
+        (ea, ua), (eb, ub) = ctx.shapes
+        dX = dX.contiguous()
+        d_wa = d_wb = d_ba = d_bb = None
+        if ctx.needs_input_grad[0]:
+            ta = torch.zeros((ua, ea), dtype=torch.float32, device=dX.device)
+            native.scatter_add_rows(dX[:, :ea], idx_a, ta)
+            d_wa = ta.t()
+        if ctx.needs_input_grad[3]:
+            tb = torch.zeros((ub, eb), dtype=torch.float32, device=dX.device)
+            native.scatter_add_rows(dX[:, ea:], idx_b, tb)
+            d_wb = tb.t()
+        if (ctx.has_bias[0] and ctx.needs_input_grad[1]) or (ctx.has_bias[1] and ctx.needs_input_grad[4]):
+            db = native.colsum(dX)
+            d_ba = db[:ea] if ctx.has_bias[0] and ctx.needs_input_grad[1] else None
+            d_bb = db[ea:] if ctx.has_bias[1] and ctx.needs_input_grad[4] else None
+        return d_wa, d_ba, None, d_wb, d_bb, None
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu):

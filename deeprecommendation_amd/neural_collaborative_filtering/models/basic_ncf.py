@@ -11,7 +11,8 @@ import torch
 from torch import nn
 
 from ... import native
-from ..util import build_MLP_layers, mlp_linears, params_version, require_gpu, row_major_embedding_, use_native
+from ..util import (build_MLP_layers, is_row_major_embedding, mlp_linears, params_version, require_gpu, row_major_embedding_,
+                    use_native)
 from .base import NCF
 
 
@@ -152,7 +153,7 @@ class BasicNCF(_ScoringMixin, NCF):
         """Training step (dropout active, autograd recording).  On CUDA tensors the gather and the Linear(+ReLU) layers run
         forward AND backward on the HIP kernels through deeprecommendation_amd.autograd; on CPU it is plain torch."""
         if X_user.is_cuda and not getattr(self, "train_with_torch_ops", False):
-            from ...autograd import GatherColumnsFn, LinearFn, mlp_train
+            from ...autograd import GatherColumnsConcatFn, GatherColumnsFn, LinearFn, mlp_train
             ue, ie = self.user_embeddings[0], self.item_embeddings[0]
             if indexed:
                 # The parameters live in nn.Linear layout [E, U] (checkpoint compatibility), so a training step gathers
@@ -160,8 +161,12 @@ class BasicNCF(_ScoringMixin, NCF):
                 # passes: 13.6 ms per step at 1 M users).  GatherColumnsFn reads the B columns and, backward, scatters the
                 # gradient straight into a zeroed [E, U] tensor; torch's `W.t()[idx]` backward sorts the ids and makes two
                 # table-sized copies on the way (1.3 ms of a 3.9 ms step).
-                x = torch.cat((GatherColumnsFn.apply(ue.weight, ue.bias, X_user.contiguous()),
-                               GatherColumnsFn.apply(ie.weight, ie.bias, X_item.contiguous())), dim=1)
+                if is_row_major_embedding(ue.weight) and is_row_major_embedding(ie.weight):
+                    # both embeddings + the concat as one gather; gradient rows scattered from the halves of dX
+                    x = GatherColumnsConcatFn.apply(ue.weight, ue.bias, X_user.contiguous(), ie.weight, ie.bias, X_item.contiguous())
+                else:
+                    x = torch.cat((GatherColumnsFn.apply(ue.weight, ue.bias, X_user.contiguous()),
+                                   GatherColumnsFn.apply(ie.weight, ie.bias, X_item.contiguous())), dim=1)
             else:
                 x = torch.cat((LinearFn.apply(X_user.float(), ue.weight, ue.bias, False),
                                LinearFn.apply(X_item.float(), ie.weight, ie.bias, False)), dim=1)

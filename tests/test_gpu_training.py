@@ -141,6 +141,41 @@ def test_gather_columns_autograd_block(gpu):
     assert float((b1.grad.cpu() - b2.grad).abs().max()) <= 1e-5 * float(b2.grad.abs().max())
 
 
+@pytest.mark.parametrize("biases", [(True, True), (True, False), (False, False)])
+def test_gather_columns_concat_autograd_block(gpu, biases):
+    """GatherColumnsConcatFn (both id-major embedding parameters + the concat as one gather) == torch's
+    cat(Wa.t()[ia] + ba, Wb.t()[ib] + bb): forward bit-exact, weight gradients 1e-6 (float atomics), bias gradients 1e-5;
+    different widths, hot ids, optional biases."""
+    from deeprecommendation_amd.autograd import GatherColumnsConcatFn
+    g = torch.Generator().manual_seed(2)
+    Ea, Eb, Ua, Ub, B = 64, 32, 400, 150, 2500
+    Wa0, Wb0 = torch.randn(Ea, Ua, generator=g), torch.randn(Eb, Ub, generator=g)
+    ba0 = torch.randn(Ea, generator=g) if biases[0] else None
+    bb0 = torch.randn(Eb, generator=g) if biases[1] else None
+    ia, ib = torch.randint(0, Ua, (B,), generator=g), torch.randint(0, Ub, (B,), generator=g)
+    ia[:300], ib[100:500] = 3, 149
+    dY = torch.randn(B, Ea + Eb, generator=g)
+    # id-major storage ([U, E] buffers), nn.Linear shape [E, U] as transpose views
+    Wa1, Wb1 = Wa0.t().contiguous().to(gpu).t().requires_grad_(), Wb0.t().contiguous().to(gpu).t().requires_grad_()
+    ba1 = ba0.clone().to(gpu).requires_grad_() if biases[0] else None
+    bb1 = bb0.clone().to(gpu).requires_grad_() if biases[1] else None
+    y1 = GatherColumnsConcatFn.apply(Wa1, ba1, ia.to(gpu), Wb1, bb1, ib.to(gpu))
+    y1.backward(dY.to(gpu))
+    Wa2, Wb2 = Wa0.clone().requires_grad_(), Wb0.clone().requires_grad_()
+    ba2 = ba0.clone().requires_grad_() if biases[0] else None
+    bb2 = bb0.clone().requires_grad_() if biases[1] else None
+    ya, yb = Wa2.t()[ia], Wb2.t()[ib]
+    y2 = torch.cat((ya + ba2 if biases[0] else ya, yb + bb2 if biases[1] else yb), dim=1)
+    y2.backward(dY)
+    assert torch.equal(y1.detach().cpu(), y2.detach())
+    for got, ref in ((Wa1.grad, Wa2.grad), (Wb1.grad, Wb2.grad)):
+        assert got.shape == ref.shape
+        assert float((got.cpu() - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-6
+    for got, ref, has in ((ba1, ba2, biases[0]), (bb1, bb2, biases[1])):
+        if has:
+            assert float((got.grad.cpu() - ref.grad).abs().max()) <= 1e-5 * float(ref.grad.abs().max())
+
+
 @pytest.mark.parametrize("wd", [0.0, 1e-2])
 def test_fused_adam_matches_torch_adam(gpu, wd):
     """deeprecommendation_amd.optim.FusedAdam (one kernel per tensor) follows torch.optim.Adam (train.py:55) step for
