@@ -5,7 +5,7 @@ layers; loss, dropout masks and the optimizer stay torch ops (the reference's tr
   GatherConcatFn : forward ncf_gather_concat;  backward ncf_scatter_add_rows into dense table gradients
   LinearFn       : forward ncf_linear_forward (ReLU fused in the epilogue);
                    backward dX = dY . W (row-streaming GEMM with W^T), dW = dY^T . X (ncf_gemm_tn, ordered split over
-                   the batch), db = ncf_colsum, ReLU mask = ncf_relu_backward
+                   the batch), db = ncf_colsum, ReLU mask = ncf_relu_backward_out
 """
 import torch
 
@@ -130,7 +130,7 @@ class LinearFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         dY = dY.contiguous()
         if ctx.relu:
-            dY = native.relu_backward_(dY.clone(), y)
+            dY = native.relu_backward(dY, y)   # one pass into a new buffer: the incoming gradient is not ours to modify
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
             dX = native.linear_act(dY, w.t().contiguous(), None, False)   # dX = dY . W

@@ -62,6 +62,7 @@ SIGNATURES = {
     "ncf_colsum_workspace_bytes": (_c_size, [_c_i64, _c_int]),
     "ncf_colsum": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_size, _c_p]),
     "ncf_relu_backward": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_p]),
+    "ncf_relu_backward_out": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_p]),
     "ncf_scatter_add_rows": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_l2_normalize_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p]),
     "ncf_gather_cols": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
@@ -599,6 +600,19 @@ def relu_backward_(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
     _, _, ldy = _rows2d(Y, "Y")
     _check(lib.ncf_relu_backward(_ptr(dY), ldd, _ptr(Y), ldy, M, N, _stream(dY)))
     return dY
+
+
+def relu_backward(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """dY masked by Y > 0 into a NEW tensor (dY untouched)."""
+    lib = load_library()
+    _dev(dY, "dY"), _dev(Y, "Y")
+    M, N, ldd = _rows2d(dY, "dY")
+    M2, N2, ldy = _rows2d(Y, "Y")
+    if (M, N) != (M2, N2):
+        raise ValueError("dY and Y shapes disagree")
+    out = torch.empty((M, N), dtype=torch.float32, device=dY.device)
+    _check(lib.ncf_relu_backward_out(_ptr(dY), ldd, _ptr(Y), ldy, _ptr(out), N, M, N, _stream(dY)))
+    return out
 
 
 def scatter_add_rows(src: torch.Tensor, idx: Optional[torch.Tensor], dst: torch.Tensor) -> torch.Tensor:

@@ -259,7 +259,7 @@ int ncf_l2_normalize_rows(const float* dev_x, int64_t ldx, int64_t R, int E, flo
  *   dX = dY . W            : ncf_mlp_forward(n_layers = 1) with the transposed weight (no dedicated entry)
  *   dW = dY^T . X          : ncf_gemm_tn(A = dY (M, N1), B = X (M, N2)) -> (N1, N2); ordered split over M, deterministic
  *   db = column sums of dY : ncf_colsum
- *   ReLU                   : ncf_relu_backward zeroes dY where the forward output was <= 0
+ *   ReLU                   : ncf_relu_backward zeroes dY where the forward output was <= 0 (ncf_relu_backward_out: into a new buffer)
  *   embedding rows         : ncf_scatter_add_rows  dst[idx[p], :] += src[p, :]  (float atomics: order-dependent last bits)
  * ------------------------------------------------------------------------------------------------ */
 /* out = act(x . W^T + b) for ONE layer with the activation selectable (relu != 0 -> ReLU): the single-layer form of
@@ -273,6 +273,9 @@ size_t ncf_colsum_workspace_bytes(int64_t M, int N);
 int ncf_colsum(const float* dev_X, int64_t ldx, int64_t M, int N, float* dev_out, void* dev_workspace, size_t workspace_bytes,
                ncf_stream_t stream);
 int ncf_relu_backward(float* dev_dY, int64_t ld_dY, const float* dev_Y, int64_t ld_Y, int64_t M, int N, ncf_stream_t stream);
+/* out = dY where Y > 0, else 0; dY is not written (the gradient autograd hands over may be shared). */
+int ncf_relu_backward_out(const float* dev_dY, int64_t ld_dY, const float* dev_Y, int64_t ld_Y, float* dev_out, int64_t ld_out, int64_t M,
+                          int N, ncf_stream_t stream);
 int ncf_scatter_add_rows(const float* dev_src, int64_t ld_src, const int64_t* dev_idx, int64_t B, int E,
                          float* dev_dst, int64_t ld_dst, int64_t rows, int32_t* dev_oob_flag, ncf_stream_t stream);
 

@@ -141,6 +141,24 @@ def test_gather_columns_autograd_block(gpu):
     assert float((b1.grad.cpu() - b2.grad).abs().max()) <= 1e-5 * float(b2.grad.abs().max())
 
 
+@pytest.mark.parametrize("M,N", [(1000, 256), (77, 30), (1, 4), (513, 129)])
+def test_relu_backward_out_of_place(gpu, M, N):
+    """ncf_relu_backward_out: dY masked by Y > 0 into a new buffer (16-byte path and scalar path, strided dY), equal to the
+    in-place entry and to torch; the incoming gradient is left untouched."""
+    from deeprecommendation_amd import native
+    g = torch.Generator().manual_seed(M + N)
+    wide = torch.randn(M, N + 8, generator=g).to(gpu)
+    dY = wide[:, :N] if N % 4 == 0 else wide[:, 1:N + 1]       # row stride != N; second form is not 16-byte aligned
+    Y = torch.relu(torch.randn(M, N, generator=g)).to(gpu)
+    keep = dY.clone()
+    out = native.relu_backward(dY, Y)
+    assert torch.equal(dY, keep)
+    assert torch.equal(out, torch.where(Y > 0, dY, torch.zeros_like(dY)))
+    assert torch.equal(out, native.relu_backward_(dY.clone(), Y))
+    with pytest.raises(ValueError):
+        native.relu_backward(dY, Y[:, :-1] if N > 1 else Y.new_zeros(M, 2))
+
+
 @pytest.mark.parametrize("biases", [(True, True), (True, False), (False, False)])
 def test_gather_columns_concat_autograd_block(gpu, biases):
     """GatherColumnsConcatFn (both id-major embedding parameters + the concat as one gather) == torch's
