@@ -133,7 +133,10 @@ class LinearFn(torch.autograd.Function):
             dY = native.relu_backward(dY, y)   # one pass into a new buffer: the incoming gradient is not ours to modify
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
-            dX = native.linear_act(dY, w.t().contiguous(), None, False)   # dX = dY . W
+            if w.shape[0] == 1:
+                dX = dY * w          # 1-wide output layer: dX is the outer product (one exact product per element, no GEMM)
+            else:
+                dX = native.linear_act(dY, w.t().contiguous(), None, False)   # dX = dY . W
         if ctx.needs_input_grad[1]:
             dW = native.gemm_tn(dY, x)                                   # dW = dY^T . X
         if ctx.has_bias and ctx.needs_input_grad[2]:
