@@ -144,15 +144,53 @@ class LinearFn(torch.autograd.Function):
         return dX, dW, db, None
 
 
+class LinearReluDropoutFn(torch.autograd.Function):
+    """dropout(relu(x W^T + b), p) — the reference's hidden-layer block in training mode (util.py:12-17) — as ONE autograd
+    node.  Forward: the HIP Linear with the ReLU in its epilogue, then torch's dropout (its Philox stream, so a seeded run
+    draws the masks it would draw with plain torch ops).  Only the OUTPUT z is kept: z > 0 exactly where the ReLU was
+    active and the element survived, so the backward of both is ``dz * 1/(1-p)`` masked by ``z > 0`` — one pass of
+    ncf_relu_backward_out instead of torch's masked-scale kernel plus the ReLU mask, and neither the pre-dropout
+    activation nor the mask is stored."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, p):
+        x = x.contiguous()
+        w = weight.contiguous()
+        z = torch.nn.functional.dropout(native.linear_act(x, w, None if bias is None else bias.contiguous(), True), p, True)
+        ctx.scale = 1.0 / (1.0 - p)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, z)
+        return z
+
+    @staticmethod
+    def backward(ctx, dZ):
+        x, w, z = ctx.saved_tensors
+        dY = native.relu_backward(dZ.contiguous(), z, ctx.scale)
+        dX = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dX = native.linear_act(dY, w.t().contiguous(), None, False)
+        if ctx.needs_input_grad[1]:
+            dW = native.gemm_tn(dY, x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = native.colsum(dY)
+        return dX, dW, db, None
+
+
 def mlp_train(seq: torch.nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     """A build_MLP_layers Sequential (Linear, [ReLU, Dropout?, Linear]*) applied with the HIP autograd blocks: every
-    Linear that is followed by a ReLU fuses it; Dropout modules run as the torch ops they are."""
+    Linear that is followed by a ReLU fuses it, and a training-mode Dropout behind that joins the same node
+    (LinearReluDropoutFn); any other module runs as the torch op it is."""
     mods = list(seq)
     i = 0
     while i < len(mods):
         m = mods[i]
         if isinstance(m, torch.nn.Linear):
             fuse = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU)
+            drop = mods[i + 2] if fuse and i + 2 < len(mods) and isinstance(mods[i + 2], torch.nn.Dropout) else None
+            if drop is not None and drop.training and 0.0 < drop.p < 1.0 and not drop.inplace:
+                x = LinearReluDropoutFn.apply(x, m.weight, m.bias, float(drop.p))
+                i += 3
+                continue
             x = LinearFn.apply(x, m.weight, m.bias, fuse)
             i += 2 if fuse else 1
         else:

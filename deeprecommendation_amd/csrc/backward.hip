@@ -103,11 +103,13 @@ __global__ void relu_backward_kernel(float* __restrict__ dY, int64_t ldd, const 
     }
 }
 
-// out[m][n] = Y[m][n] > 0 ? dY[m][n] : 0, dY left untouched (autograd hands gradients it may still share): one pass
-// instead of a copy followed by the in-place mask.  VEC: 16-byte accesses when widths, strides and bases allow.
+// out[m][n] = Y[m][n] > 0 ? scale * dY[m][n] : 0, dY left untouched (autograd hands gradients it may still share): one
+// pass instead of a copy followed by the in-place mask.  With Y = dropout(relu(.)) and scale = 1/(1-p) this is the backward
+// of ReLU AND of the dropout behind it (Y > 0 exactly where the ReLU was active and the element was kept).
+// VEC: 16-byte accesses when widths, strides and bases allow.
 template <bool VEC>
 __global__ void relu_backward_out_kernel(const float* __restrict__ dY, int64_t ldd, const float* __restrict__ Y, int64_t ldy,
-                                         float* __restrict__ out, int64_t ldo, int64_t M, int N) {
+                                         float* __restrict__ out, int64_t ldo, int64_t M, int N, float scale) {
     const int W = VEC ? N / 4 : N;
     const int64_t total = M * W;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -118,10 +120,10 @@ __global__ void relu_backward_out_kernel(const float* __restrict__ dY, int64_t l
             const f32x4 y = *reinterpret_cast<const f32x4*>(Y + m * ldy + 4 * c);
             f32x4 r;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = y[j] > 0.f ? g[j] : 0.f;
+            for (int j = 0; j < 4; ++j) r[j] = y[j] > 0.f ? g[j] * scale : 0.f;
             *reinterpret_cast<f32x4*>(out + m * ldo + 4 * c) = r;
         } else {
-            out[m * ldo + c] = Y[m * ldy + c] > 0.f ? dY[m * ldd + c] : 0.f;
+            out[m * ldo + c] = Y[m * ldy + c] > 0.f ? dY[m * ldd + c] * scale : 0.f;
         }
     }
 }
@@ -276,14 +278,14 @@ extern "C" int ncf_relu_backward(float* dY, int64_t ldd, const float* Y, int64_t
 }
 
 extern "C" int ncf_relu_backward_out(const float* dY, int64_t ldd, const float* Y, int64_t ldy, float* out, int64_t ldo, int64_t M, int N,
-                                     ncf_stream_t stream) {
+                                     float scale, ncf_stream_t stream) {
     if (M == 0) return NCF_OK;
     if (N <= 0 || M < 0 || !dY || !Y || !out || ldd < N || ldy < N || ldo < N) return fail(NCF_EINVAL, "ncf_relu_backward_out: bad argument");
     const bool vec = N % 4 == 0 && ldd % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && aligned16(dY) && aligned16(Y) && aligned16(out);
     int64_t blocks = (M * (vec ? N / 4 : N) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (vec) hipLaunchKernelGGL(relu_backward_out_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dY, ldd, Y, ldy, out, ldo, M, N);
-    else hipLaunchKernelGGL(relu_backward_out_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dY, ldd, Y, ldy, out, ldo, M, N);
+    if (vec) hipLaunchKernelGGL(relu_backward_out_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dY, ldd, Y, ldy, out, ldo, M, N, scale);
+    else hipLaunchKernelGGL(relu_backward_out_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dY, ldd, Y, ldy, out, ldo, M, N, scale);
     return check_launch("ncf_relu_backward_out");
 }
 

@@ -62,7 +62,7 @@ SIGNATURES = {
     "ncf_colsum_workspace_bytes": (_c_size, [_c_i64, _c_int]),
     "ncf_colsum": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_size, _c_p]),
     "ncf_relu_backward": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_p]),
-    "ncf_relu_backward_out": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_p]),
+    "ncf_relu_backward_out": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, ctypes.c_float, _c_p]),
     "ncf_scatter_add_rows": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_l2_normalize_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p]),
     "ncf_gather_cols": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
@@ -602,8 +602,8 @@ def relu_backward_(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
     return dY
 
 
-def relu_backward(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
-    """dY masked by Y > 0 into a NEW tensor (dY untouched)."""
+def relu_backward(dY: torch.Tensor, Y: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """scale * dY masked by Y > 0 into a NEW tensor (dY untouched)."""
     lib = load_library()
     _dev(dY, "dY"), _dev(Y, "Y")
     M, N, ldd = _rows2d(dY, "dY")
@@ -611,7 +611,7 @@ def relu_backward(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
     if (M, N) != (M2, N2):
         raise ValueError("dY and Y shapes disagree")
     out = torch.empty((M, N), dtype=torch.float32, device=dY.device)
-    _check(lib.ncf_relu_backward_out(_ptr(dY), ldd, _ptr(Y), ldy, _ptr(out), N, M, N, _stream(dY)))
+    _check(lib.ncf_relu_backward_out(_ptr(dY), ldd, _ptr(Y), ldy, _ptr(out), N, M, N, float(scale), _stream(dY)))
     return out
 
 

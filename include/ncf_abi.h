@@ -273,9 +273,10 @@ size_t ncf_colsum_workspace_bytes(int64_t M, int N);
 int ncf_colsum(const float* dev_X, int64_t ldx, int64_t M, int N, float* dev_out, void* dev_workspace, size_t workspace_bytes,
                ncf_stream_t stream);
 int ncf_relu_backward(float* dev_dY, int64_t ld_dY, const float* dev_Y, int64_t ld_Y, int64_t M, int N, ncf_stream_t stream);
-/* out = dY where Y > 0, else 0; dY is not written (the gradient autograd hands over may be shared). */
+/* out = scale * dY where Y > 0, else 0; dY is not written (the gradient autograd hands over may be shared).  scale = 1 is the
+ * ReLU backward; with Y = dropout(relu(.)) and scale = 1 / (1 - p) it is the backward of the ReLU and the dropout together. */
 int ncf_relu_backward_out(const float* dev_dY, int64_t ld_dY, const float* dev_Y, int64_t ld_Y, float* dev_out, int64_t ld_out, int64_t M,
-                          int N, ncf_stream_t stream);
+                          int N, float scale, ncf_stream_t stream);
 int ncf_scatter_add_rows(const float* dev_src, int64_t ld_src, const int64_t* dev_idx, int64_t B, int E,
                          float* dev_dst, int64_t ld_dst, int64_t rows, int32_t* dev_oob_flag, ncf_stream_t stream);
 

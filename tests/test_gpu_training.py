@@ -121,7 +121,7 @@ def test_gather_concat_autograd_block(gpu):
 
 def test_gather_columns_autograd_block(gpu):
     """GatherColumnsFn (Linear-layout embedding parameter W [E, U]) == torch's `W.t()[idx] + b` forward (bit-exact) and
-    backward (float atomics: duplicates of an id add in any order -> 1e-6), incl. repeated ids."""
+    backward (float atomics: duplicates of an id add in any order -> 4e-6), incl. repeated ids."""
     from deeprecommendation_amd.autograd import GatherColumnsFn
     g = torch.Generator().manual_seed(0)
     E, U, B = 64, 500, 3000
@@ -137,8 +137,43 @@ def test_gather_columns_autograd_block(gpu):
     y2 = W2.t()[idx] + b2
     y2.backward(dY)
     assert torch.equal(y1.detach().cpu(), y2.detach())
-    assert float((W1.grad.cpu() - W2.grad).abs().max()) <= 1e-6 * float(W2.grad.abs().max()) + 1e-6
+    assert float((W1.grad.cpu() - W2.grad).abs().max()) <= 4e-6 * float(W2.grad.abs().max()) + 1e-6   # 200 duplicates, any order
     assert float((b1.grad.cpu() - b2.grad).abs().max()) <= 1e-5 * float(b2.grad.abs().max())
+
+
+def test_linear_relu_dropout_block_matches_torch_ops_with_the_same_seed(gpu):
+    """LinearReluDropoutFn draws torch's own dropout mask (same seed, same shape -> same Philox stream), so output and
+    all three gradients can be compared with relu -> dropout in plain torch ops on the GPU: 1e-5."""
+    from deeprecommendation_amd.autograd import LinearReluDropoutFn, mlp_train
+    g = torch.Generator().manual_seed(9)
+    B, K, N, p = 4096, 128, 256, 0.3
+    x0, w0, b0 = torch.randn(B, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    dZ = torch.randn(B, N, generator=g).to(gpu)
+    leaves = lambda: [t.clone().to(gpu).requires_grad_() for t in (x0, w0, b0)]
+    x1, w1, b1 = leaves()
+    torch.manual_seed(123)
+    z1 = LinearReluDropoutFn.apply(x1, w1, b1, p)
+    z1.backward(dZ)
+    x2, w2, b2 = leaves()
+    torch.manual_seed(123)
+    z2 = torch.nn.functional.dropout(torch.relu(torch.nn.functional.linear(x2, w2, b2)), p, True)
+    z2.backward(dZ)
+    from test_gpu_basic import assert_close
+    assert float((z1 == 0).float().mean()) > p          # dropped + inactive
+    assert torch.equal(z1 == 0, z2 == 0)
+    assert_close(z1, z2)
+    for a, b in ((x1.grad, x2.grad), (w1.grad, w2.grad), (b1.grad, b2.grad)):
+        assert_close(a, b, rtol=2e-5)
+    # mlp_train picks the fused node for Linear -> ReLU -> Dropout(train) and the plain one in eval mode / p = 0
+    seq = torch.nn.Sequential(torch.nn.Linear(K, N), torch.nn.ReLU(), torch.nn.Dropout(p), torch.nn.Linear(N, 1)).to(gpu)
+    xin = x0.to(gpu).requires_grad_()
+    out = mlp_train(seq, xin)
+    assert "LinearFn" in type(out.grad_fn).__name__ and "LinearReluDropoutFn" in type(out.grad_fn.next_functions[0][0]).__name__
+    seq.eval()
+    ev = mlp_train(seq, xin)
+    assert "LinearReluDropoutFn" not in type(ev.grad_fn.next_functions[0][0]).__name__
+    out.sum().backward()
+    assert xin.grad is not None and torch.isfinite(xin.grad).all()
 
 
 @pytest.mark.parametrize("M,N", [(1000, 256), (77, 30), (1, 4), (513, 129)])
@@ -155,6 +190,7 @@ def test_relu_backward_out_of_place(gpu, M, N):
     assert torch.equal(dY, keep)
     assert torch.equal(out, torch.where(Y > 0, dY, torch.zeros_like(dY)))
     assert torch.equal(out, native.relu_backward_(dY.clone(), Y))
+    assert torch.equal(native.relu_backward(dY, Y, 1.25), torch.where(Y > 0, dY * 1.25, torch.zeros_like(dY)))
     with pytest.raises(ValueError):
         native.relu_backward(dY, Y[:, :-1] if N > 1 else Y.new_zeros(M, 2))
 
@@ -162,7 +198,7 @@ def test_relu_backward_out_of_place(gpu, M, N):
 @pytest.mark.parametrize("biases", [(True, True), (True, False), (False, False)])
 def test_gather_columns_concat_autograd_block(gpu, biases):
     """GatherColumnsConcatFn (both id-major embedding parameters + the concat as one gather) == torch's
-    cat(Wa.t()[ia] + ba, Wb.t()[ib] + bb): forward bit-exact, weight gradients 1e-6 (float atomics), bias gradients 1e-5;
+    cat(Wa.t()[ia] + ba, Wb.t()[ib] + bb): forward bit-exact, weight gradients 4e-6 (float atomics), bias gradients 1e-5;
     different widths, hot ids, optional biases."""
     from deeprecommendation_amd.autograd import GatherColumnsConcatFn
     g = torch.Generator().manual_seed(2)
@@ -188,7 +224,8 @@ def test_gather_columns_concat_autograd_block(gpu, biases):
     assert torch.equal(y1.detach().cpu(), y2.detach())
     for got, ref in ((Wa1.grad, Wa2.grad), (Wb1.grad, Wb2.grad)):
         assert got.shape == ref.shape
-        assert float((got.cpu() - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-6
+        # up to 400 duplicates of one id are added by float atomics in any order: ~sqrt(400) * 2^-24 of the sum
+        assert float((got.cpu() - ref).abs().max()) <= 4e-6 * float(ref.abs().max()) + 1e-6
     for got, ref, has in ((ba1, ba2, biases[0]), (bb1, bb2, biases[1])):
         if has:
             assert float((got.grad.cpu() - ref.grad).abs().max()) <= 1e-5 * float(ref.grad.abs().max())
