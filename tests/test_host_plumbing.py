@@ -1,4 +1,6 @@
 """CPU tests of the host-side mirror: providers, datasets, eval metrics, model contract (no GPU compute)."""
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -360,3 +362,19 @@ def test_early_stopping_follows_the_reference_rule():
             assert es.best == best and es.strikes == times
             if want == "stop":
                 break
+
+
+def test_host_thread_cap_never_raises_the_count_and_respects_the_share():
+    """util.cap_host_threads: torch's intra-op pool is lowered to the CPU share (affinity mask capped by the cgroup quota)
+    when it exceeds it, and never raised."""
+    from deeprecommendation_amd.neural_collaborative_filtering.util import cap_host_threads, host_cpu_share
+    share = host_cpu_share()
+    assert 1 <= share <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(1)
+        assert cap_host_threads() == 1                      # below the share: untouched
+        torch.set_num_threads(share + 3)
+        assert cap_host_threads() == share == torch.get_num_threads()
+    finally:
+        torch.set_num_threads(before)
