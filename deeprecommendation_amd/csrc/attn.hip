@@ -535,30 +535,48 @@ __global__ __launch_bounds__(1024) void group_small_kernel(const int64_t* __rest
         else atomicAdd(&counts[r], 1);
     }
     __syncthreads();
-    for (int64_t base = 0; base < R; base += 1024) {       // B <= 32768: the sums fit 32 bits
-        const int64_t i = base + threadIdx.x;
-        const int c = i < R ? counts[i] : 0;
-        const int wgs = (c + ppw - 1) / ppw;
-        sa[threadIdx.x] = c;
-        sb[threadIdx.x] = wgs;
-        __syncthreads();
-        const int n = (int)(R - base < 1024 ? R - base : 1024);
-        for (int off = 1; off < n; off <<= 1) {            // Hillis-Steele inclusive scan over the rows present
-            const int va = threadIdx.x >= off ? sa[threadIdx.x - off] : 0;
-            const int vb = threadIdx.x >= off ? sb[threadIdx.x - off] : 0;
-            __syncthreads();
-            sa[threadIdx.x] += va;
-            sb[threadIdx.x] += vb;
-            __syncthreads();
+    // Exclusive scans of the row counts and of the per-row workgroup counts (B <= 32768: the sums fit 32 bits).  Each
+    // thread owns a contiguous run of rows: serial sums over its run, ONE block scan of the 1024 run totals (wave scans by
+    // shuffles + a scan of the 16 wave totals: three barriers whatever R is — the blockwise Hillis-Steele scan this
+    // replaces spent ~23 barriers per 1024 rows, 14 of the kernel's 20 us at R = 4096), then the run is written out.
+    {
+        const int per = (int)((R + 1023) / 1024);
+        const int64_t lo = (int64_t)threadIdx.x * per;
+        const int64_t hi = lo + per < R ? lo + per : R;
+        int ta = 0, tb = 0;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int c = counts[i];
+            ta += c;
+            tb += (c + ppw - 1) / ppw;
         }
-        if (i < R) {
-            const int ea = carry_a + sa[threadIdx.x] - c, eb = carry_b + sb[threadIdx.x] - wgs;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int ia = ta, ib = tb;                                   // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int ua = __shfl_up(ia, off, 64), ub = __shfl_up(ib, off, 64);
+            if (lane >= off) { ia += ua; ib += ub; }
+        }
+        if (lane == 63) { sa[wave] = ia; sb[wave] = ib; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int ca = 0, cb = 0;
+            for (int w = 0; w < 16; ++w) {                      // exclusive scan of the 16 wave totals
+                const int va = sa[w], vb = sb[w];
+                sa[w] = ca; sb[w] = cb;
+                ca += va; cb += vb;
+            }
+            carry_a = ca; carry_b = cb;
+        }
+        __syncthreads();
+        int ea = sa[wave] + ia - ta, eb = sb[wave] + ib - tb;   // exclusive prefix of this thread's run
+        for (int64_t i = lo; i < hi; ++i) {
+            const int c = counts[i];
             grp_ptr[i] = ea;
             wg_ptr[i] = eb;
             cursor[i] = ea;
+            ea += c;
+            eb += (c + ppw - 1) / ppw;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) { carry_a += sa[n - 1]; carry_b += sb[n - 1]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) { grp_ptr[R] = carry_a; wg_ptr[R] = carry_b; }

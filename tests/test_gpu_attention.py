@@ -289,6 +289,29 @@ def test_attention_grouped_large_batch_matches_per_pair(native, gpu):
     native.check_oob(gpu)
 
 
+@pytest.mark.parametrize("R", [1, 63, 1000, 1024, 1025, 4096, 4097, 9999, 32768, 40000])
+@pytest.mark.parametrize("B,ppw", [(1, 8), (4096, 32), (30000, 16)])
+def test_group_pairs_is_a_row_ordered_permutation(native, gpu, R, B, ppw):
+    """ncf_group_pairs over the row counts of every dispatch: LDS counters (R <= 4096), global counters (R <= 32768, run
+    lengths that do not divide R), the multi-launch path above; rows concentrated on a few ids and spread over all of them.
+    grp_ptr / wg_ptr must be the exclusive scans of the row counts / per-row workgroup counts and pair_ids a permutation
+    of the pairs listed row by row."""
+    g = torch.Generator(device=gpu).manual_seed(R * 31 + B)
+    for spread in (min(R, 7), R):
+        pair_row = torch.randint(0, spread, (B,), device=gpu, generator=g)
+        if spread == R and R > 1:
+            pair_row[0], pair_row[-1] = R - 1, 0          # first and last row in use
+        grp_ptr, pair_ids, wg_ptr = native.group_pairs(pair_row, R, ppw)
+        counts = torch.bincount(pair_row, minlength=R)
+        assert int(grp_ptr[0]) == 0 and int(wg_ptr[0]) == 0
+        assert torch.equal(grp_ptr[1:] - grp_ptr[:-1], counts)
+        assert torch.equal(wg_ptr[1:] - wg_ptr[:-1], (counts + ppw - 1) // ppw)
+        assert torch.equal(torch.sort(pair_ids).values, torch.arange(B, device=gpu))
+        listed = pair_row[pair_ids]
+        assert bool((listed[1:] >= listed[:-1]).all())
+    native.check_oob(gpu)
+
+
 @pytest.mark.parametrize("cos", [False, True])
 def test_candidates_as_rows_of_the_catalogue(native, gpu, cos):
     """AttentionNCF.forward with the candidates given as RowsOf(rated_items, index) (embeddings taken from the catalogue
