@@ -106,9 +106,9 @@ def _resident_batches(res, batch_size, device):
     """Yield device-resident batches ``(*inputs[s:e], y[s:e])`` of whole-file host tensors.  Uploads go RESIDENT_CHUNK_BATCHES
     batches at a time through two reused sets of pinned staging + device buffers on a side stream, one chunk ahead of the
     kernels that consume them: the compute stream waits on the chunk's copy event, the copy stream on the event that marks
-    the previous user of the buffer set as enqueued-and-done.  No per-sample Python, no per-batch host-to-device copy, and
-    no allocation per chunk (side-stream allocations handed to the compute stream with ``record_stream`` made every later
-    allocation poll their events: measured 130 -> 400-900 us of host time per batch on long passes)."""
+    the previous user of the buffer set as enqueued-and-done.  No per-sample Python, no per-batch host-to-device copy, no
+    allocation or page-pinning per chunk, and the staging copy is a plain memcpy (an OpenMP copy on the thread that enqueues
+    GPU work is what exposed the thread-pool throttling util.cap_host_threads guards against)."""
     host = (*res.tensors, res.targets)
     n = len(res.targets)
     if n == 0:
@@ -203,8 +203,8 @@ def eval_model(model, test_dataset: PointwiseDataset, batch_size, ranking=False,
         res["rmse"] = sqrt(res["mse"])
     ranked = None
     if np.issubdtype(test_dataset.samples['userId'].to_numpy().dtype, np.integer):
-        # sorts and segment sums of the ranking metrics on the model's device (nine host lexsorts cost 4.4 s per million
-        # samples; three device sort pairs serve all three cut-offs)
+        # sorts and segment sums of the ranking metrics on the model's device (nine host lexsorts cost 1.3-4.4 s per
+        # million samples; three device sort pairs serve all three cut-offs)
         ranked = eval_ranking_device(test_dataset.samples['userId'].to_numpy(), test_dataset.samples['rating'].to_numpy(dtype=np.float64),
                                      pred_dev if pred_dev is not None else pred, tuple(cutoffs), device)
     else:
