@@ -215,19 +215,38 @@ class AttentionNCF(_ScoringMixin, NCF):
         cache = self._refresh()  # ONE parameter fingerprint per forward (it walks the module tree: ~12 us of host time)
         li, lu = self.ItemEmbeddings[0], self.UserEmbeddings[0]
         rated_emb, pr, proj = self.precompute_catalog(rated_items, cache)
+        pc_kept = None
+        # never inside a HIP-graph capture: a hit would leave the candidate projections out of the captured graph
+        keep = not isinstance(candidate_items, RowsOf) and not torch.cuda.is_current_stream_capturing()
         if isinstance(candidate_items, RowsOf):
             if candidate_items.table is rated_items:
                 cand_emb = rated_emb.index_select(0, candidate_items.index)   # same Linear, already applied to every row
             else:
                 cand_emb = native.linear(candidate_items.materialise().float().contiguous(), li.weight.detach(), li.bias.detach())
         else:
-            cand_emb = native.linear(candidate_items.float().contiguous(), li.weight.detach(), li.bias.detach())
+            # The candidate projections depend only on the candidate tensor and the weights: a serving loop scores every user
+            # against the SAME catalogue tensor (webapp/backend.py:78-121), so the last one seen is kept (like the rated-item
+            # catalogue above).  The key holds address, shape and version; the tensor itself is kept alive with the entry, so
+            # the address cannot be recycled under it, and an in-place edit bumps the version.
+            ckey = (candidate_items.data_ptr(), tuple(candidate_items.shape), candidate_items.dtype, candidate_items._version)
+            kept = cache.get("candidates") if keep else None
+            if kept is not None and kept[0] == ckey:
+                cand_emb, pc_kept = kept[1], kept[2]
+            else:
+                cand_emb = native.linear(candidate_items.float().contiguous(), li.weight.detach(), li.bias.detach())
         ratings = user_matrix if isinstance(user_matrix, SparseRatings) else SparseRatings.from_dense(user_matrix)
-        if self.use_cos_sim_instead:
-            mode, pc, w1, b1 = native.ATT_COS, native.l2_normalize_rows(cand_emb), None, 0.0
+        if pc_kept is not None:
+            pc = pc_kept
+        elif self.use_cos_sim_instead:
+            pc = native.l2_normalize_rows(cand_emb)
         else:
             wc, _, b0 = self._att_split(cache)
             pc = native.linear(cand_emb, wc, b0)
+        if keep and pc_kept is None:
+            cache["candidates"] = (ckey, cand_emb, pc, candidate_items)
+        if self.use_cos_sim_instead:
+            mode, w1, b1 = native.ATT_COS, None, 0.0
+        else:
             if self.att_dense:
                 l1 = self.AttentionNet[-1]
                 if "att_out" not in cache:

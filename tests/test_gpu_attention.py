@@ -339,3 +339,46 @@ def test_candidates_as_rows_of_the_catalogue(native, gpu, cos):
     assert_close(lazy, dense)
     assert_close(other, dense)
     assert lazy.shape == (B, 1)
+
+
+def test_candidate_projections_are_kept_for_a_repeated_candidate_tensor(native, gpu):
+    """Serving shape (webapp/backend.py:78-121): every request scores the SAME catalogue tensor for another user.  The
+    second call reuses the candidate projections (no F -> IE Linear launched), gives the same scores as a fresh model, and
+    an in-place edit of the tensor, a new tensor, or a weight update invalidate the kept entry."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
+    g = torch.Generator().manual_seed(8)
+    I, F, B = 400, 48, 2048
+    feats = torch.randn(I, F, generator=g).to(gpu)
+    cands = torch.randn(B, F, generator=g).to(gpu)
+    torch.manual_seed(4)
+    m = AttentionNCF(item_dim=F, item_emb=64, user_emb=64, att_dense=32, mlp_dense_layers=[128]).to(gpu).eval()
+    fresh = AttentionNCF(item_dim=F, item_emb=64, user_emb=64, att_dense=32, mlp_dense_layers=[128]).to(gpu).eval()
+    fresh.load_state_dict(m.state_dict())
+
+    def user_matrix(seed):
+        gg = torch.Generator().manual_seed(seed)
+        row = torch.where(torch.rand(I, generator=gg) < 0.2, torch.randn(I, generator=gg), torch.zeros(I))
+        return row.repeat(B, 1).to(gpu)
+
+    calls = []
+    real = native.linear
+    def counting(x, *a, **k):
+        calls.append(tuple(x.shape))
+        return real(x, *a, **k)
+    with torch.no_grad():
+        first = m(cands, feats, user_matrix(1))
+        native.linear = counting
+        try:
+            second = m(cands, feats, user_matrix(2))
+        finally:
+            native.linear = real
+        assert (B, F) not in calls and (B, 64) not in calls          # neither candidate Linear ran again
+        assert torch.equal(second, fresh(cands, feats, user_matrix(2)))
+        assert torch.equal(first, fresh(cands, feats, user_matrix(1)))
+        cands[0].mul_(2.0)                                           # in-place edit -> recomputed
+        assert torch.equal(m(cands, feats, user_matrix(2)), fresh(cands.clone(), feats, user_matrix(2)))
+        other = cands.clone()
+        assert torch.equal(m(other, feats, user_matrix(3)), fresh(other, feats, user_matrix(3)))
+        m.ItemEmbeddings[0].bias.add_(0.5)                          # weight update -> everything derived is dropped
+        fresh.load_state_dict(m.state_dict())
+        assert torch.equal(m(other, feats, user_matrix(3)), fresh(other.clone(), feats, user_matrix(3)))
