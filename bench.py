@@ -1,7 +1,7 @@
 """bench.py — BASELINE.json headline metric: scored user-item pairs/s of the NCF scoring hot path on MI355X.
 
-Workload (config.workload = "cfg2"): BASELINE.json configs[1] — BasicNCF, 1 M users x 100 k items, emb_dim 64,
-batch 65 536, fp32, MLP [256, 128] -> 1; synthetic seeded tables / weights / indices (no datasets offline).
+Workload of the headline line (config.workload = "cfg2"): BASELINE.json configs[1] — BasicNCF, 1 M users x 100 k items,
+emb_dim 64, batch 65 536, fp32, MLP [256, 128] -> 1; synthetic seeded tables / weights / indices (no datasets offline).
 A "step" = one forward of one batch through the product path (BasicNCF.forward on int64 positions ->
 ncf_score_fused through the C ABI), inputs already resident in HBM.
 
@@ -9,17 +9,32 @@ ncf_score_fused through the C ABI), inputs already resident in HBM.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-N > 1: replicas (pairs are independent; tables + MLP replicated, the batch is split, no data-path
-collective) -> weak scaling, value = N * 65 536 * K / max-over-ranks time.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment STARTS the N ranks itself: this process, before it has made
+any GPU call, runs the torch.distributed.run command above as a child and exits with its code (a process that has
+touched the GPU is never re-exec'd).  Under torchrun, WORLD_SIZE must equal --gpus.
 
-The JSON line carries `roofline` (dominant kernel = the fused gather+MLP kernel, fp32-MFMA-bound, timed live with
-HIP events on the launch stream), `gather_roofline` (the standalone K1 gather kernel vs the 8 TB/s HBM peak — the
-second half of BASELINE's metric) and `cpu_baseline` (the CPU oracle's table formulation timed on the host cores,
-rank 0, N = 1 only, bounded sample).
+N > 1, headline line: replicas (pairs are independent; tables + MLP replicated, the batch is split, no
+data-path collective) -> weak scaling, value = N * 65 536 * K / max-over-ranks time.
+
+`other_configs` (default run only; `--workload cfg2` prints the headline line alone, `--workload cfgK` that config alone):
+  N = 1: cfg 3 (AttentionNCF), cfg 4 (LightGCN propagation, 100 M directed edges), cfg 5 (bf16 emb 128, the 28 GB of
+         tables on one GPU), each with its own `roofline` and `cpu_baseline`;
+  N > 1: the two configs that SHARD — cfg 5 (row-sharded tables, all-to-all over RCCL; pipelined / serial / de-duplicating
+         exchange side by side) and cfg 4 (partitioned LightGCN: destination blocks + all-gather and edge split +
+         all-reduce side by side).
+Every secondary config runs after the headline measurement, in the same processes, and a failure there is recorded in
+its entry instead of taking the line down.
+
+Every `roofline.frac` = algorithmic work per launch / the kernel's ISOLATED launch duration (HIP events around single
+launches on the launch stream, a synchronisation between launches — what rocprofv3's serialised kernel trace
+reports, and what `profiles/<round>_*` hold for the same command); the back-to-back figure (a launch's ramp overlapping
+the previous launch's tail) is kept as `us_back_to_back`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,8 +50,30 @@ FLOP_PER_PAIR = 2 * (2 * E * HIDDEN[0] + HIDDEN[0] * HIDDEN[1] + HIDDEN[1])     
 FUSED_BYTES_PER_PAIR = 2 * E * 4 + 2 * 8 + 4                                       # 532 B   
 GATHER_BYTES_PER_PAIR = 2 * (2 * E * 4) + 2 * 8                                    # 1040 B: rows read + rows written + ids
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 N_BATCHES = 16  # distinct index batches cycled through, so no step re-reads the previous step's rows from cache
+PROFILE_TAG = "r02"   # profiles/<tag>_*: the rocprofv3 summaries of THIS round's bench command (tools/profile*.sh)
+
+
+class Ctx:
+    """Process placement of one bench run."""
+
+    def __init__(self, device, rank, world, dist):
+        self.device, self.rank, self.world, self.dist = device, rank, world, dist
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if self.dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.device if self.dist.get_backend() == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
 
 def make_model(device):
@@ -65,22 +102,24 @@ def make_batches(device, rank):
             for _ in range(N_BATCHES)]
 
 
-def profile_digest(kernel_prefix):
-    """HBM traffic per launch from the committed rocprofv3 PMC pass (profiles/<tag>_digest.json, written by
-    tools/summarize_profile.py: FETCH_SIZE x2-corrected + WRITE_SIZE, per the gfx950 guide) and rocprof's own mean
-    duration of the same kernel.  None when no profile of this kernel is committed."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_digest.json"))):
-        try:
-            d = json.load(open(path))
-        except (OSError, ValueError):
-            continue
-        for name, k in d.get("kernels", {}).items():
-            if name.startswith(kernel_prefix) and "fetch_bytes" in k:
-                best = {"traffic": k.get("fetch_bytes", 0.0) + k.get("write_bytes", 0.0),
-                        "rocprof_avg_us": k.get("rocprof_avg_us"), "profile": os.path.basename(path)}
-    return best
+def profile_digest(kernel_prefix, context):
+    """HBM traffic per launch from the committed rocprofv3 PMC passes of THIS bench context
+    (profiles/<PROFILE_TAG>_<context>_digest.json, written by tools/summarize_profile.py: FETCH_SIZE x2-corrected +
+    WRITE_SIZE, per the gfx950 guide) and rocprof's own mean duration of the same kernel.  None when that profile is not
+    committed (never another context's)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{context}_digest.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    for name, k in d.get("kernels", {}).items():
+        if name.startswith(kernel_prefix):
+            out = {"rocprof_avg_us": k.get("rocprof_avg_us"), "profile": os.path.basename(path)}
+            if "fetch_bytes" in k or "write_bytes" in k:
+                out["traffic"] = k.get("fetch_bytes", 0.0) + k.get("write_bytes", 0.0)
+                out["fetch_bytes"], out["write_bytes"] = k.get("fetch_bytes"), k.get("write_bytes")
+            return out
+    return None
 
 
 def host_cores():
@@ -94,6 +133,35 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+# ---------------------------------------------------------------------------------------------------- kernel timing
+def back_to_back_us(fn, reps=100, settle=60):
+    """Mean duration of `reps` back-to-back launches (HIP events on the launch stream = torch's current stream)."""
+    for _ in range(settle):  # the chip takes milliseconds to settle its clock after a change of kernel
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def isolated_us(fn, reps=100, settle=60):
+    """Mean duration of single launches, the stream drained between them (HIP events around each launch): the kernel's
+    isolated duration, the figure rocprofv3's serialised kernel trace reports."""
+    for _ in range(settle):
+        fn()
+    torch.cuda.synchronize()
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in pairs:
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+    return sum(e0.elapsed_time(e1) for e0, e1 in pairs) * 1e3 / reps
 
 
 def cpu_baseline(model, seconds=12.0):
@@ -164,27 +232,182 @@ def zipf_indices(n_rows, count, alpha, device, seed):
     return perm[rank]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fold", action="store_true",
-                    help="opt-in: fold the first MLP layer into the tables (BasicNCF.set_fold_first_layer); NOT the default line")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "train2"],
-                    help="cfg2 = BASELINE headline (default); cfg3 / cfg4 = the other single-GPU configs (bench_extra.py)")
-    args = ap.parse_args()
-    # torch sizes its OpenMP pool from the visible CPUs (256 on the GPU box, of which the cgroup grants 16): surplus workers
-    # spinning after a host-side parallel region get the enqueueing thread throttled — keep the pool within the share
-    torch.set_num_threads(min(torch.get_num_threads(), host_cores()))
-    if args.workload != "cfg2":
-        import bench_extra
-        return bench_extra.main(args)
+# ---------------------------------------------------------------------------------------------------- cfg 2 (headline)
+def run_cfg2(args, ctx):
+    from deeprecommendation_amd import native
+    device, rank, world = ctx.device, ctx.rank, ctx.world
+    model = make_model(device)
+    if args.fold:
+        model.set_fold_first_layer(True)
+    batches = make_batches(device, rank)
 
+    def step(k):
+        iu, ii = batches[k % N_BATCHES]
+        return model(iu, ii)
+
+    warm = max(args.warmup, 300)
+    with torch.no_grad():
+        # untimed: the requested warm-up steps, topped up to >= 300 so that the chip's clock has settled on this kernel
+        # before the timed region (DVFS takes milliseconds to settle; measured: 50 timed steps straight after 5 warm-ups
+        # read 805 M pairs/s, after the settling 905 M) — the timed region is exactly --steps steps either way
+        for k in range(warm):
+            step(k)
+        ctx.barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        ctx.barrier()
+        elapsed = time.perf_counter() - t0
+        native.check_oob(device)
+    elapsed = ctx.max_over_ranks(elapsed)
+
+    # --- roofline of the dominant kernel (the kernels run on torch's current stream, so torch.cuda.Event brackets them)
+    packed = model._packed_mlp()
+    tu, ti = model._table("user", model.user_embeddings[0]), model._table("item", model.item_embeddings[0])
+    outbuf = torch.empty((B, 1), dtype=torch.float32, device=device)
+    cyc = [0]
+
+    def fused():
+        k = cyc[0] = (cyc[0] + 1) % N_BATCHES
+        native.score_fused(tu, batches[k][0], ti, batches[k][1], packed, out=outbuf)
+
+    fused_b2b = back_to_back_us(fused)
+    fused_iso = isolated_us(fused)
+    achieved_tf = FLOP_PER_PAIR * B / (fused_iso * 1e-6) / 1e12
+    fold_info = None
+    if args.fold:
+        PA, PB, tail = model._folded(tu, ti, "MLP")
+        fus = isolated_us(lambda: native.score_folded(PA, batches[1][0], PB, batches[1][1], tail, out=outbuf))
+        ex_flop = 2 * (HIDDEN[0] * HIDDEN[1] + HIDDEN[1])
+        fold_info = {"kernel": "score_folded_direct_kernel<256,128>", "bound": "mfma", "us_per_launch": fus,
+                     "executed_flop_per_pair": ex_flop, "achieved": ex_flop * B / (fus * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": ex_flop * B / (fus * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "algorithmic_bytes_per_pair": 2 * HIDDEN[0] * 4 + 2 * 8 + 4, "traffic": None,
+                     "note": "opt-in folded first layer: executes 65 792 of the 131 328 FLOP/pair; the roofline object "
+                             "above is the default (unfolded) kernel measured in the same process"}
+
+    gbuf = torch.empty((B, 2 * E), dtype=torch.float32, device=device)
+
+    def gather():
+        k = cyc[0] = (cyc[0] + 1) % N_BATCHES
+        native.gather_concat(tu, batches[k][0], ti, batches[k][1], out=gbuf)
+
+    gather_b2b = back_to_back_us(gather)
+    gather_iso = isolated_us(gather)
+    gather_gbs = GATHER_BYTES_PER_PAIR * B / (gather_iso * 1e-6) / 1e9
+
+    # ---- SURVEY §8d cfg 2 variants: Zipf(1.05) user ids, and the [256]-only MLP (train_model.py:40-42 default) ----
+    zu = zipf_indices(U, B, 1.05, device, 2024)
+    zi = batches[0][1]
+    zipf_fused_us = isolated_us(lambda: native.score_fused(tu, zu, ti, zi, packed, out=outbuf))
+    lin = [m for m in model.MLP if isinstance(m, torch.nn.Linear)]
+    g2 = torch.Generator(device=device).manual_seed(7)
+    w_last = (torch.rand((1, HIDDEN[0]), device=device, generator=g2) * 2 - 1) / HIDDEN[0] ** 0.5
+    packed256 = native.PackedMLP([lin[0].weight, w_last], [lin[0].bias, lin[2].bias])
+    h256_us = isolated_us(lambda: native.score_fused(tu, batches[1][0], ti, batches[1][1], packed256, out=outbuf))
+    zipf_gather_us = isolated_us(lambda: native.gather_concat(tu, zu, ti, zi, out=gbuf))
+    # opt-in variant (BasicNCF.set_fold_first_layer): layer 1 folded into 256-wide tables; reported beside the default
+    # line, never as `value` (its results agree with the oracle to 1e-5 but are not bit-identical to the default kernel's)
+    fold_variant = None
+    if fold_info is None and native.folded_supported(HIDDEN[0], HIDDEN[1]):
+        try:
+            PAv, PBv, tailv = model._folded(tu, ti, "MLP")
+            fv_us = isolated_us(lambda: native.score_folded(PAv, batches[1][0], PBv, batches[1][1], tailv, out=outbuf))
+            fold_variant = {"fused_us_per_launch": fv_us, "fused_pairs_per_s": B / (fv_us * 1e-6),
+                            "executed_flop_per_pair": 2 * (HIDDEN[0] * HIDDEN[1] + HIDDEN[1]),
+                            "bytes_per_pair": 2 * HIDDEN[0] * 4 + 2 * 8 + 4,
+                            "table_bytes": int(PAv.numel() + PBv.numel()) * 4}
+            del PAv, PBv
+        except Exception as exc:  # the variant must never take the default line down
+            fold_variant = {"error": str(exc)}
+
+    if rank != 0:
+        return None
+    dig_f = profile_digest("ncf::score_fused_f32_kernel<128, 256, 128>", "cfg2") or {}
+    dig_g = profile_digest("ncf::gather_concat", "cfg2") or {}
+    total_pairs = world * B * args.steps
+    line = {
+        "metric": "scored user-item pairs/sec",
+        "value": total_pairs / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": warm,
+        "warmup_requested": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "cfg2: BasicNCF 1M users x 100k items, emb_dim=64, batch=65536/GPU, fp32, MLP 128-256-128-1"
+                               + (" [first MLP layer FOLDED into 256-wide tables: 65 792 executed FLOP and 2068 B per pair]" if args.fold else ""),
+                   "parallelism": f"replicas x{world} (tables+MLP replicated, batch split, no collective)"},
+        "roofline": {"kernel": "score_fused_f32_kernel<128,256,128>", "bound": "mfma", "achieved": achieved_tf,
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
+                     "traffic": dig_f.get("traffic"), "us_per_launch": fused_iso, "us_back_to_back": fused_b2b,
+                     "algorithmic_flop_per_pair": FLOP_PER_PAIR, "algorithmic_bytes_per_pair": FUSED_BYTES_PER_PAIR,
+                     "algorithmic_bytes_per_launch": FUSED_BYTES_PER_PAIR * B,
+                     "rocprof_avg_us": dig_f.get("rocprof_avg_us"), "profile": dig_f.get("profile"),
+                     "note": "us_per_launch (and frac) = isolated launches, HIP events around each, stream drained between them; "
+                             "us_back_to_back = 100 launches in a row (a launch's ramp overlaps the previous launch's tail)"},
+        "gather_roofline": {"kernel": "gather_concat (standalone K1)", "bound": "hbm", "achieved": gather_gbs,
+                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gather_gbs / PEAK_HBM_GBS,
+                            "traffic": dig_g.get("traffic"), "us_per_launch": gather_iso, "us_back_to_back": gather_b2b,
+                            "ids": "uniform", "algorithmic_bytes_per_pair": GATHER_BYTES_PER_PAIR,
+                            "algorithmic_bytes_per_launch": GATHER_BYTES_PER_PAIR * B,
+                            "rocprof_avg_us": dig_g.get("rocprof_avg_us"), "profile": dig_g.get("profile")},
+    }
+    flop256 = 2 * (2 * E * HIDDEN[0] + HIDDEN[0])
+    line["variants"] = {
+        "zipf_1.05_users": {"fused_us_per_launch": zipf_fused_us, "fused_pairs_per_s": B / (zipf_fused_us * 1e-6),
+                            "gather_us_per_launch": zipf_gather_us,
+                            "gather_GBps_algorithmic": GATHER_BYTES_PER_PAIR * B / (zipf_gather_us * 1e-6) / 1e9,
+                            "note": "hot rows are cache hits: the algorithmic rate may exceed the HBM peak; not the roofline figure"},
+        "mlp_256_only": {"fused_us_per_launch": h256_us, "fused_pairs_per_s": B / (h256_us * 1e-6),
+                         "flop_per_pair": flop256, "frac_of_fp32_mfma_peak": flop256 * B / (h256_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+    }
+    if fold_variant is not None:
+        line["variants"]["folded_first_layer_opt_in"] = fold_variant
+    if fold_info is not None:
+        line["folded_roofline"] = fold_info
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(model)
+        line["cpu_baseline_reference_formulation"] = cpu_baseline_dense_cfg1()
+    return line
+
+
+# ---------------------------------------------------------------------------------------------------- launch / main
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a torchrun environment: start the N ranks as children (torch.distributed.run), relay their
+    output (rank 0 prints the one JSON line) and exit with their code.  Nothing in this process has touched the GPU:
+    torch.cuda.device_count() does not initialise it on this image."""
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("NCF_BENCH_SINGLE_DEVICE") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def init_ctx(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, "
+                         "or run `python bench.py --gpus N` alone and let it start the ranks")
+    if os.environ.get("NCF_BENCH_ANNOUNCE") == "1":
+        print(f"bench.py: rank {rank} of {world} (local rank {local_rank})", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if os.environ.get("NCF_BENCH_SINGLE_DEVICE") == "1":
@@ -199,182 +422,103 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    return Ctx(device, rank, world, dist)
 
+
+def _guarded(name, fn, args, ctx):
+    """A secondary config never takes the line down: its failure is recorded (every rank reaches the next config)."""
+    t0 = time.perf_counter()
+    try:
+        res = fn(args, ctx)
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+        res = {"error": f"{type(exc).__name__}: {exc}", "traceback_tail": traceback.format_exc()[-600:]}
+    torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    if isinstance(res, dict):
+        res["bench_wall_s"] = time.perf_counter() - t0
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fold", action="store_true",
+                    help="opt-in: fold the first MLP layer into the tables (BasicNCF.set_fold_first_layer); NOT the default line")
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5", "train2"],
+                    help="one config alone (cfg2 = the headline line without other_configs); default: headline + other_configs")
+    args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus is not None and args.gpus > 1:
+            sys.exit(launch_ranks(args, sys.argv[1:]))
+        args.gpus = 1
+    # torch sizes its OpenMP pool from the visible CPUs (256 on the GPU box, of which the cgroup grants 16): surplus workers
+    # spinning after a host-side parallel region get the enqueueing thread throttled — keep the pool within the share
+    torch.set_num_threads(min(torch.get_num_threads(), host_cores()))
+    ctx = init_ctx(args)
     from deeprecommendation_amd import native
     native.load_library()
-    model = make_model(device)
-    if args.fold:
-        model.set_fold_first_layer(True)
-    batches = make_batches(device, rank)
+    import bench_extra
+    user_steps, user_warmup = args.steps, args.warmup
 
-    def step(k):
-        iu, ii = batches[k % N_BATCHES]
-        return model(iu, ii)
+    def sized(steps, warmup):
+        a = argparse.Namespace(**vars(args))
+        a.steps = user_steps if user_steps is not None else steps
+        a.warmup = user_warmup if user_warmup is not None else warmup
+        return a
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    with torch.no_grad():
-        # untimed: the requested warm-up steps, topped up to >= 300 so that the chip's clock has settled on this kernel
-        # before the timed region (DVFS takes milliseconds to settle; measured: 50 timed steps straight after 5 warm-ups
-        # read 805 M pairs/s, after the settling 905 M) — the timed region is exactly --steps steps either way
-        for k in range(max(args.warmup, 300)):
-            out = step(k)
-        barrier()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        t0 = time.perf_counter()
-        ev[0].record()
-        for k in range(args.steps):
-            out = step(k)
-        ev[1].record()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        native.check_oob(device)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # --- roofline of the dominant kernel: per-launch duration from HIP events around back-to-back launches on the
-    # launch stream (the kernels run on torch's current stream, so torch.cuda.Event brackets exactly them).
-    iu, ii = batches[0]
-    packed = model._packed_mlp()
-    tu, ti = model._table("user", model.user_embeddings[0]), model._table("item", model.item_embeddings[0])
-    outbuf = torch.empty((B, 1), dtype=torch.float32, device=device)
-    reps = 100
-    for k in range(60):
-        native.score_fused(tu, batches[k % N_BATCHES][0], ti, batches[k % N_BATCHES][1], packed, out=outbuf)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for k in range(reps):
-        native.score_fused(tu, batches[k % N_BATCHES][0], ti, batches[k % N_BATCHES][1], packed, out=outbuf)
-    e1.record()
-    torch.cuda.synchronize()
-    fused_us = e0.elapsed_time(e1) * 1e3 / reps
-    achieved_tf = FLOP_PER_PAIR * B / (fused_us * 1e-6) / 1e12
-    fold_info = None
-    if args.fold:
-        PA, PB, tail = model._folded(tu, ti, "MLP")
-        for k in range(5):
-            native.score_folded(PA, batches[k % N_BATCHES][0], PB, batches[k % N_BATCHES][1], tail, out=outbuf)
-        e0.record()
-        for k in range(reps):
-            native.score_folded(PA, batches[k % N_BATCHES][0], PB, batches[k % N_BATCHES][1], tail, out=outbuf)
-        e1.record()
-        torch.cuda.synchronize()
-        fus = e0.elapsed_time(e1) * 1e3 / reps
-        ex_flop = 2 * (HIDDEN[0] * HIDDEN[1] + HIDDEN[1])
-        fold_info = {"kernel": "score_folded_direct_kernel<256,128>", "bound": "mfma", "us_per_launch": fus,
-                     "executed_flop_per_pair": ex_flop, "achieved": ex_flop * B / (fus * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": ex_flop * B / (fus * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                     "algorithmic_bytes_per_pair": 2 * HIDDEN[0] * 4 + 2 * 8 + 4, "traffic": None,
-                     "note": "opt-in folded first layer: executes 65 792 of the 131 328 FLOP/pair; the roofline object "
-                             "above is the default (unfolded) kernel measured in the same process"}
-
-    gbuf = torch.empty((B, 2 * E), dtype=torch.float32, device=device)
-    for k in range(60):  # settle the clock on this (memory-bound) kernel before timing it
-        native.gather_concat(tu, batches[k % N_BATCHES][0], ti, batches[k % N_BATCHES][1], out=gbuf)
-    e0.record()
-    for k in range(reps):
-        native.gather_concat(tu, batches[k % N_BATCHES][0], ti, batches[k % N_BATCHES][1], out=gbuf)
-    e1.record()
-    torch.cuda.synchronize()
-    gather_us = e0.elapsed_time(e1) * 1e3 / reps
-    gather_gbs = GATHER_BYTES_PER_PAIR * B / (gather_us * 1e-6) / 1e9
-
-    # ---- SURVEY §8d cfg 2 variants: Zipf(1.05) user ids, and the [256]-only MLP (train_model.py:40-42 default) ----
-    def per_launch(fn, n=100):
-        for _ in range(60):  # the chip takes milliseconds to settle its clock after a change of kernel: warm up long enough
-            fn()
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / n
-
-    zu = zipf_indices(U, B, 1.05, device, 2024)
-    zi = batches[0][1]
-    per_launch(lambda: native.score_fused(tu, batches[2][0], ti, batches[2][1], packed, out=outbuf))  # back to this kernel's clock state
-    zipf_fused_us = per_launch(lambda: native.score_fused(tu, zu, ti, zi, packed, out=outbuf))
-    lin = [m for m in model.MLP if isinstance(m, torch.nn.Linear)]
-    g2 = torch.Generator(device=device).manual_seed(7)
-    w_last = (torch.rand((1, HIDDEN[0]), device=device, generator=g2) * 2 - 1) / HIDDEN[0] ** 0.5
-    packed256 = native.PackedMLP([lin[0].weight, w_last], [lin[0].bias, lin[2].bias])
-    h256_us = per_launch(lambda: native.score_fused(tu, batches[1][0], ti, batches[1][1], packed256, out=outbuf))
-    zipf_gather_us = per_launch(lambda: native.gather_concat(tu, zu, ti, zi, out=gbuf))
-    # opt-in variant (BasicNCF.set_fold_first_layer): layer 1 folded into 256-wide tables; reported beside the default
-    # line, never as `value` (its results agree with the oracle to 1e-5 but are not bit-identical to the default kernel's)
-    fold_variant = None
-    if fold_info is None and native.folded_supported(HIDDEN[0], HIDDEN[1]):
-        try:
-            PAv, PBv, tailv = model._folded(tu, ti, "MLP")
-            fv_us = per_launch(lambda: native.score_folded(PAv, batches[1][0], PBv, batches[1][1], tailv, out=outbuf))
-            fold_variant = {"fused_us_per_launch": fv_us, "fused_pairs_per_s": B / (fv_us * 1e-6),
-                            "executed_flop_per_pair": 2 * (HIDDEN[0] * HIDDEN[1] + HIDDEN[1]),
-                            "bytes_per_pair": 2 * HIDDEN[0] * 4 + 2 * 8 + 4,
-                            "table_bytes": int(PAv.numel() + PBv.numel()) * 4}
-            del PAv, PBv
-        except Exception as exc:  # the variant must never take the default line down
-            fold_variant = {"error": str(exc)}
-
-    if rank == 0:
-        dig_f = profile_digest("ncf::score_fused_f32_kernel<128, 256, 128>") or {}
-        dig_g = profile_digest("ncf::gather_concat_vec16") or {}
-        total_pairs = world * B * args.steps
-        line = {
-            "metric": "scored user-item pairs/sec",
-            "value": total_pairs / elapsed,
-            "unit": "pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "cfg2: BasicNCF 1M users x 100k items, emb_dim=64, batch=65536/GPU, fp32, MLP 128-256-128-1"
-                                   + (" [first MLP layer FOLDED into 256-wide tables: 65 792 executed FLOP and 2068 B per pair]" if args.fold else ""),
-                       "parallelism": f"replicas x{world} (tables+MLP replicated, batch split, no collective)"},
-            "roofline": {"kernel": "score_fused_f32_kernel<128,256,128>", "bound": "mfma", "achieved": achieved_tf,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": dig_f.get("traffic"), "us_per_launch": fused_us,
-                         "algorithmic_flop_per_pair": FLOP_PER_PAIR, "algorithmic_bytes_per_pair": FUSED_BYTES_PER_PAIR,
-                         "algorithmic_bytes_per_launch": FUSED_BYTES_PER_PAIR * B,
-                         "rocprof_avg_us_isolated": dig_f.get("rocprof_avg_us"), "profile": dig_f.get("profile"),
-                         "note": "us_per_launch = HIP events around 100 back-to-back launches (a launch's ramp overlaps the "
-                                 "previous launch's tail); rocprof serialises dispatches and reports the isolated duration"},
-            "gather_roofline": {"kernel": "gather_concat_vec16<32,1>", "bound": "hbm", "achieved": gather_gbs,
-                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gather_gbs / PEAK_HBM_GBS,
-                                "traffic": dig_g.get("traffic"), "us_per_launch": gather_us,
-                                "algorithmic_bytes_per_pair": GATHER_BYTES_PER_PAIR,
-                                "algorithmic_bytes_per_launch": GATHER_BYTES_PER_PAIR * B,
-                                "rocprof_avg_us_isolated": dig_g.get("rocprof_avg_us"), "profile": dig_g.get("profile")},
-        }
-        flop256 = 2 * (2 * E * HIDDEN[0] + HIDDEN[0])
-        line["variants"] = {
-            "zipf_1.05_users": {"fused_us_per_launch": zipf_fused_us, "fused_pairs_per_s": B / (zipf_fused_us * 1e-6),
-                                "gather_us_per_launch": zipf_gather_us,
-                                "gather_GBps_algorithmic": GATHER_BYTES_PER_PAIR * B / (zipf_gather_us * 1e-6) / 1e9},
-            "mlp_256_only": {"fused_us_per_launch": h256_us, "fused_pairs_per_s": B / (h256_us * 1e-6),
-                             "flop_per_pair": flop256, "frac_of_fp32_mfma_peak": flop256 * B / (h256_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS},
-        }
-        if fold_variant is not None:
-            line["variants"]["folded_first_layer_opt_in"] = fold_variant
-        if fold_info is not None:
-            line["folded_roofline"] = fold_info
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model)
-            line["cpu_baseline_reference_formulation"] = cpu_baseline_dense_cfg1()
+    if args.workload not in (None, "cfg2"):
+        fn, (st, wu) = bench_extra.WORKLOADS[args.workload]
+        line = fn(sized(st, wu), ctx)
+    else:
+        line = run_cfg2(sized(400, 40), ctx)
+        if args.workload is None:
+            others = {}
+            if ctx.rank == 0:
+                line["other_configs"] = others
+            names = ("cfg3", "cfg4", "cfg5") if ctx.world == 1 else ("cfg5", "cfg4")
+            for name in names:
+                fn, (st, wu) = bench_extra.WORKLOADS[name]
+                a = argparse.Namespace(**vars(args))
+                a.steps, a.warmup = st, wu          # the secondary configs keep their own step counts
+                # a secondary config that hangs (a collective whose peer died) must not cost the headline measurement: past
+                # its deadline every rank leaves, rank 0 printing the line with what it has
+                guard = _Deadline(SECONDARY_DEADLINE_S, name, line if ctx.rank == 0 else None, others)
+                res = _guarded(name, fn, a, ctx)
+                guard.cancel()
+                if ctx.rank == 0:
+                    others[name] = res
+    if ctx.rank == 0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
+
+
+SECONDARY_DEADLINE_S = 420.0
+
+
+class _Deadline:
+    def __init__(self, seconds, name, line, others):
+        import threading
+        self.name, self.line, self.others = name, line, others
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def cancel(self):
+        self.timer.cancel()
+
+    def _fire(self):
+        if self.line is not None:
+            self.others[self.name] = {"error": f"no result within {SECONDARY_DEADLINE_S:.0f} s: abandoned"}
+            print(json.dumps(self.line), flush=True)
+        os._exit(0)
 
 
 if __name__ == "__main__":

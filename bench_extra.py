@@ -1,37 +1,43 @@
-"""Secondary workloads of BASELINE.json (not the headline line bench.py prints by default):
+"""Secondary workloads of BASELINE.json (bench.py's `other_configs`, or alone with `--workload`):
 
-  --workload cfg3   AttentionNCF forward: 100k-item catalogue, 256 rated items per user, IE = UE = 64, A = 128,
-                    F = 2094, B = 4096 (user, candidate) pairs per step; catalogue projections precomputed once
-                    (eval-time precompute, SURVEY §8d cfg 3).  Unit: pairs/s.
-  --workload cfg4   GraphNCF 3-layer LightGCN propagation: 1 M users + 100 k items, 50 M interactions = 100 M directed
-                    edges (items ~ Zipf(1.0)), D = 128, hetero, mean readout.  Unit: directed edges/s
-                    (3 layers x 100 M per step).
-Same JSON contract as bench.py (one line; roofline of the dominant kernel; no cpu_baseline here).
+  cfg3   AttentionNCF forward: 100k-item catalogue, 256 rated items per user, IE = UE = 64, A = 128, F = 2094, B = 4096
+         (user, candidate) pairs per step; catalogue projections precomputed once (eval-time precompute, SURVEY §8d cfg 3).
+         Unit: pairs/s.  Replicas only: single-GPU entry.
+  cfg4   GraphNCF 3-layer LightGCN propagation: 1 M users + 100 k items, 50 M interactions = 100 M directed edges
+         (items ~ Zipf(1.0)), D = 128, hetero, mean readout.  Unit: directed edges/s (3 layers x 100 M per step).
+         N > 1: PartitionedLightGCN, destination blocks + all-gather and edge split + all-reduce side by side.
+  cfg5   BasicNCF 100 M users x 10 M items, emb 128 bf16, MLP 256-256-128-1.  N = 1: both tables on the one GPU (no
+         exchange).  N > 1: user table row-sharded, all-to-all exchange over RCCL; pipelined / serial / unique side by side.
+  train2 training step on the cfg-2 shape.
+Every function returns the JSON object (rank 0; None elsewhere) with the same contract as bench.py's line.
 """
-import json
 import os
 import time
 
 import torch
 
 
-def _time_steps(step, warmup, steps):
-    # untimed: the warm-up steps, continued until ~30 ms have been enqueued so that the clock has settled on this
-    # workload's kernels (short steps only; DVFS takes milliseconds); the timed region is exactly `steps` steps
+def _time_steps(step, warmup, steps, ctx=None):
+    """(wall seconds of exactly `steps` steps, warm-up steps actually run).  Untimed: the warm-up steps, continued until
+    ~30 ms have been enqueued so that the clock has settled on this workload's kernels (short steps only; DVFS takes
+    milliseconds).  Barrier + synchronize on both sides; the caller takes the max over ranks."""
     t_w = time.perf_counter()
     k = 0
     while k < warmup or (time.perf_counter() - t_w < 0.03 and k < 2000):
         step(k)
         k += 1
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if ctx is not None:
+        ctx.barrier()
+    else:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    e0.record()
-    for k in range(steps):
-        step(k)
-    e1.record()
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0, e0.elapsed_time(e1) * 1e-3
+    for j in range(steps):
+        step(j)
+    if ctx is not None:
+        ctx.barrier()
+    else:
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0, k
 
 
 def _cpu_median_s(fn, reps, warm=2):
@@ -48,36 +54,27 @@ def _cpu_median_s(fn, reps, warm=2):
     return sorted(ts)[len(ts) // 2], bench.host_cores()
 
 
-def _per_launch_us(fn, reps=50):
-    for _ in range(3):
-        fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
-
-
-def run_cfg4(args, device):
-    from deeprecommendation_amd import native
-    from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphData, GraphNCF, PreparedGraph
-    I, U, D, L, n = 100_000, 1_000_000, 128, 3, 50_000_000
-    g = torch.Generator(device=device).manual_seed(11)
+# ---------------------------------------------------------------------------------------------------- cfg 4
+def _cfg4_graph(device):
+    from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphData
+    I, U, n = 100_000, 1_000_000, 50_000_000
+    g = torch.Generator(device=device).manual_seed(11)     # the same graph on every rank
     p = 1.0 / torch.arange(1, I + 1, device=device, dtype=torch.float64)
     items = torch.multinomial((p / p.sum()).float(), n, replacement=True, generator=g)
     users = torch.randint(0, U, (n,), device=device, generator=g) + I
-    rating = torch.randint(1, 11, (n,), device=device, generator=g).float() * 0.5
-    attr = rating - 3.0
-    graph = GraphData(user2item_edge_index=torch.stack([users, items]), item2user_edge_index=torch.stack([items, users]),
-                      user2item_edge_attr=attr, item2user_edge_attr=attr.clone(), num_items=I, num_users=U)
-    del items, users, rating
+    attr = torch.randint(1, 11, (n,), device=device, generator=g).float() * 0.5 - 3.0
+    return GraphData(user2item_edge_index=torch.stack([users, items]), item2user_edge_index=torch.stack([items, users]),
+                     user2item_edge_attr=attr, item2user_edge_attr=attr.clone(), num_items=I, num_users=U)
+
+
+def _cfg4_model(device, L=3, D=128):
+    from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphNCF
+    I, U = 100_000, 1_000_000
     torch.manual_seed(1234)
     with torch.device("meta"):
         model = GraphNCF(item_dim=I, user_dim=U, num_gnn_layers=L, hetero=True, node_emb=D, mlp_dense_layers=[256, 128])
     model = model.to_empty(device=device).eval()
-    gg = torch.Generator(device=device).manual_seed(1234)
+    gg = torch.Generator(device=device).manual_seed(1234)  # the same weights on every rank
     with torch.no_grad():
         for prm in model.parameters():
             if prm.dim() == 2:
@@ -85,6 +82,36 @@ def run_cfg4(args, device):
                 prm.uniform_(-bound, bound, generator=gg)
             else:
                 prm.uniform_(-0.05, 0.05, generator=gg)
+    return model
+
+
+def _cfg4_cpu_baseline(model, D):
+    # CPU oracle, reference formulation (per-EDGE Linear + scatter-add, gnn_ncf.py:39-94) on a graph 100x smaller:
+    # 10 000 users x 1 000 items, 500 000 interactions (the full graph's per-edge messages alone are 51 GB)
+    from oracle import ncf_oracle as O
+    gc = torch.Generator().manual_seed(11)
+    Ic, Uc, nc = 1_000, 10_000, 500_000
+    pc_ = 1.0 / torch.arange(1, Ic + 1, dtype=torch.float64)
+    it = torch.multinomial((pc_ / pc_.sum()).float(), nc, replacement=True, generator=gc)
+    us_ = torch.randint(0, Uc, (nc,), generator=gc) + Ic
+    at = torch.randint(1, 11, (nc,), generator=gc).float() * 0.5 - 3.0
+    xc = torch.randn(Ic + Uc, D, generator=gc) * 0.05
+    cs = {k: v.detach().cpu() for k, v in model.gnn_convs[0].state_dict().items()}
+    sec, cores = _cpu_median_s(lambda: O.lightgcn_conv(xc, cs, True, torch.stack([us_, it]), torch.stack([it, us_]), at, at), reps=20, warm=5)
+    return {"value": 2 * nc / sec, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"reference formulation (per-edge Linear + index_add) of ONE layer on {Uc} users x {Ic} items, "
+                      f"{2 * nc} directed edges, D={D}, median of 20 after 5 warm-ups ({sec * 1e3:.0f} ms each), torch CPU fp32"}
+
+
+def run_cfg4(args, ctx):
+    import bench
+    if ctx.world > 1:
+        return run_cfg4_partitioned(args, ctx)
+    from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import PreparedGraph
+    device = ctx.device
+    I, U, D, L = 100_000, 1_000_000, 128, 3
+    graph = _cfg4_graph(device)
+    model = _cfg4_model(device, L, D)
     t0 = time.perf_counter()
     prep = PreparedGraph(graph, True)
     graph._prepared[("prep", True)] = prep
@@ -99,47 +126,87 @@ def run_cfg4(args, device):
         with torch.no_grad():
             return model.propagate_all(graph)
 
-    wall, _ = _time_steps(step, args.warmup, args.steps)
-    # dominant kernel: one SpMM layer
+    wall, warm = _time_steps(step, args.warmup, args.steps)
+    # dominant kernel: one SpMM layer (edge pass + the ordered partial-sum tree of the hub rows)
     conv = model.gnn_convs[0]
     x = model._node_table0(graph)
     z = conv.hoisted(x, prep)
     y = torch.empty((N, D), device=device)
-    us = _per_launch_us(lambda: prep.csr.spmm(z, y=y), reps=20)
-    gemm_us = _per_launch_us(lambda: conv.hoisted(x, prep), reps=20)
+    us = bench.isolated_us(lambda: prep.csr.spmm(z, y=y), reps=20, settle=5)
+    us_b2b = bench.back_to_back_us(lambda: prep.csr.spmm(z, y=y), reps=20, settle=5)
+    gemm_us = bench.isolated_us(lambda: conv.hoisted(x, prep), reps=20, settle=5)
     bytes_per_edge = D * 4 + 4 + 4
     alg = E * bytes_per_edge + N * D * 4  # + the output rows written once
     gbs = alg / (us * 1e-6) / 1e9
+    dig = bench.profile_digest("ncf::spmm_seg_kernel", "cfg4") or {}
+    traffic = dig.get("traffic")
     line = {"metric": "LightGCN propagated directed edges/sec", "value": L * E * args.steps / wall, "unit": "edges/s", "n_gpus": 1,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "steps": args.steps, "warmup": warm, "warmup_requested": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg4: GraphNCF {L}-layer LightGCN, {U} users x {I} items, {E} directed edges (Zipf items), D={D}, hetero, mean",
                        "graph_prep_s": prep_s, "segments": int(prep.segptr.numel() - 1)},
-            "roofline": {"kernel": f"spmm_seg_kernel<32> x{len(prep.csr.levels)} levels (edge pass + ordered partial tree)", "bound": "hbm", "achieved": gbs, "peak": 8000.0,
-                         "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None, "us_per_launch": us,
-                         "algorithmic_bytes_per_edge": bytes_per_edge, "hoisted_gemm_us": gemm_us}}
+            "roofline": {"kernel": f"spmm_seg_kernel<32> x{len(prep.csr.levels)} levels (edge pass + ordered partial tree), one layer",
+                         "bound": "hbm", "achieved": gbs, "peak": bench.PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / bench.PEAK_HBM_GBS,
+                         "traffic": traffic, "us_per_launch": us, "us_back_to_back": us_b2b,
+                         "algorithmic_bytes_per_edge": bytes_per_edge, "algorithmic_bytes_per_launch": alg,
+                         "hbm_GBps_from_counters": None if traffic is None else traffic / (us * 1e-6) / 1e9,
+                         "hbm_frac_from_counters": None if traffic is None else traffic / (us * 1e-6) / 1e9 / bench.PEAK_HBM_GBS,
+                         "rocprof_avg_us": dig.get("rocprof_avg_us"), "profile": dig.get("profile"), "hoisted_gemm_us": gemm_us,
+                         "note": "achieved / frac are ALGORITHMIC bytes (520 B per edge) over the layer's time; the 51 MB of item rows "
+                                 "(half of all source reads) are served by the Infinity Cache, so the bytes that reach HBM are fewer: "
+                                 "hbm_GBps_from_counters is the PMC figure (FETCH x2 + WRITE of the edge-pass kernel) over the same time"}}
     if not getattr(args, "no_cpu_baseline", False):
-        # CPU oracle, reference formulation (per-EDGE Linear + scatter-add, gnn_ncf.py:39-94) on a graph 100x smaller:
-        # 10 000 users x 1 000 items, 500 000 interactions (the full graph's per-edge messages alone are 51 GB)
-        from oracle import ncf_oracle as O
-        gc = torch.Generator().manual_seed(11)
-        Ic, Uc, nc = 1_000, 10_000, 500_000
-        pc_ = 1.0 / torch.arange(1, Ic + 1, dtype=torch.float64)
-        it = torch.multinomial((pc_ / pc_.sum()).float(), nc, replacement=True, generator=gc)
-        us_ = torch.randint(0, Uc, (nc,), generator=gc) + Ic
-        at = torch.randint(1, 11, (nc,), generator=gc).float() * 0.5 - 3.0
-        xc = torch.randn(Ic + Uc, D, generator=gc) * 0.05
-        cs = {k: v.detach().cpu() for k, v in model.gnn_convs[0].state_dict().items()}
-        sec, cores = _cpu_median_s(lambda: O.lightgcn_conv(xc, cs, True, torch.stack([us_, it]), torch.stack([it, us_]), at, at), reps=20, warm=5)
-        line["cpu_baseline"] = {"value": 2 * nc / sec, "unit": "edges/s", "cores": cores, "kind": "port",
-                                "sample": f"reference formulation (per-edge Linear + index_add) of ONE layer on {Uc} users x {Ic} items, "
-                                          f"{2 * nc} directed edges, D={D}, median of 20 after 5 warm-ups ({sec * 1e3:.0f} ms each), torch CPU fp32"}
-    print(json.dumps(line), flush=True)
+        line["cpu_baseline"] = _cfg4_cpu_baseline(model, D)
+    return line
 
 
-def run_cfg3(args, device):
+def run_cfg4_partitioned(args, ctx):
+    """cfg 4 at N > 1: every rank builds the same graph, keeps its partition, and one step = the full
+    3-layer propagation including the collectives.  Both partitionings are timed; value = the faster one."""
+    from deeprecommendation_amd.sharded import PartitionedLightGCN
+    device = ctx.device
+    I, U, D, L = 100_000, 1_000_000, 128, 3
+    graph = _cfg4_graph(device)
+    model = _cfg4_model(device, L, D)
+    E = 2 * int(graph.user2item_edge_index.shape[1])
+    x0 = model._node_table0(graph)
+    res = {}
+    for mode in ("dst", "edge"):
+        t0 = time.perf_counter()
+        part = PartitionedLightGCN(model, graph, mode=mode)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t0
+
+        def step(k):
+            with torch.no_grad():
+                return part.propagate(x0)
+
+        wall, warm = _time_steps(step, args.warmup, args.steps, ctx)
+        wall = ctx.max_over_ranks(wall)
+        res[mode] = {"ms_per_step": wall / args.steps * 1e3, "edges_per_s": L * E * args.steps / wall, "build_s": build_s,
+                     "local_edges_rank0": part.local_edges, "rows_rank0": part.hi - part.lo, "warmup": warm}
+        del part
+        torch.cuda.empty_cache()
+    if ctx.rank != 0:
+        return None
+    best = min(res, key=lambda m: res[m]["ms_per_step"])
+    return {"metric": "LightGCN propagated directed edges/sec", "value": res[best]["edges_per_s"], "unit": "edges/s",
+            "n_gpus": ctx.world, "steps": args.steps, "warmup": res[best]["warmup"], "ms_per_step": res[best]["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg4: GraphNCF {L}-layer LightGCN, {U} users x {I} items, {E} directed edges (Zipf items), D={D}, hetero, mean",
+                       "parallelism": f"{best} (the faster of the two below) x{ctx.world}; the graph is fixed: strong scaling"},
+            "partitionings": {"dst_blocks_all_gather": res["dst"], "edge_split_all_reduce": res["edge"],
+                              "collective_bytes_per_layer": {"dst": f"{(I + U) * D * 4 * (ctx.world - 1) // ctx.world} received per rank (direct block exchange, all links)",
+                                                            "edge": f"{2 * (ctx.world - 1) * (I + U) * D * 4 // ctx.world} moved per rank (ring all-reduce of the (N, D) partial sums)"}},
+            "roofline": None}
+
+
+# ---------------------------------------------------------------------------------------------------- cfg 3
+def run_cfg3(args, ctx):
+    import bench
     from deeprecommendation_amd import native
     from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF, SparseRatings
+    device = ctx.device
     I, B, nnz, Fdim, IE, UE, A = 100_000, 4096, 256, 2094, 64, 64, 128
     torch.manual_seed(7)
     model = AttentionNCF(item_dim=Fdim, item_emb=IE, user_emb=UE, att_dense=A, mlp_dense_layers=[256, 128]).eval().to(device)
@@ -165,9 +232,9 @@ def run_cfg3(args, device):
             cand, r = batches[k % len(batches)]
             return model(cand, catalogue, r)
 
-        wall_eager, _ = _time_steps(step, args.warmup, args.steps)
-        # the step is launch-bound from Python (a dozen 10-60 us kernels): replay it as ONE HIP graph launch per step;
-        # each step copies its batch into the graph's static buffers first
+        wall_eager, warm = _time_steps(step, args.warmup, args.steps)
+        # the step is a dozen 5-60 us kernels: also replay it as ONE HIP graph launch per step (each step copies its batch
+        # into the graph's static buffers first) and report the faster form
         wall = wall_eager
         wall_graph = None
         graph_err = None
@@ -200,23 +267,34 @@ def run_cfg3(args, device):
         bias_u = model.UserEmbeddings[0].bias.detach()
         rs = batches[0][1] if not per_pair else None
         rx = r.expanded()
-        us_pp = _per_launch_us(lambda: native.attn_forward(native.ATT_MLP, pc, pr, w1, b1, rx.rowptr, rx.col, rx.val, proj, out_bias=bias_u))
+        us_pp = bench.isolated_us(lambda: native.attn_forward(native.ATT_MLP, pc, pr, w1, b1, rx.rowptr, rx.col, rx.val, proj, out_bias=bias_u), reps=50, settle=10)
         ppw = native.default_pairs_per_wg(B)
-        grouping = None if per_pair else (native.group_pairs(rs.pair_row, rs.rowptr.numel() - 1, ppw), ppw)
-        us_g = None if per_pair else _per_launch_us(lambda: native.attn_forward_grouped(native.ATT_MLP, pc, pr, w1, b1, rs.rowptr, rs.col,
-                                                                                          rs.val, rs.pair_row, proj, out_bias=bias_u,
-                                                                                          grouping=grouping))
-        us_group_prep = None if per_pair else _per_launch_us(lambda: native.group_pairs(rs.pair_row, rs.rowptr.numel() - 1, ppw), reps=50)
-        lin_us = _per_launch_us(lambda: native.linear(cand, li.weight.detach(), li.bias.detach()))
+        us_g = us_g_b2b = us_group_prep = None
+        if not per_pair:
+            grouping = (native.group_pairs(rs.pair_row, rs.rowptr.numel() - 1, ppw), ppw)
+
+            def grouped():
+                return native.attn_forward_grouped(native.ATT_MLP, pc, pr, w1, b1, rs.rowptr, rs.col, rs.val, rs.pair_row, proj, out_bias=bias_u,
+                                                   grouping=grouping)
+
+            us_g = bench.isolated_us(grouped, reps=50, settle=20)
+            us_g_b2b = bench.back_to_back_us(grouped, reps=50, settle=20)
+            us_group_prep = bench.isolated_us(lambda: native.group_pairs(rs.pair_row, rs.rowptr.numel() - 1, ppw), reps=50, settle=5)
+        lin_us = bench.isolated_us(lambda: native.linear(cand, li.weight.detach(), li.bias.detach()), reps=50, settle=5)
     us = us_pp if per_pair else us_g
-    # per-pair kernel: every pair gathers its rated rows from cache; grouped kernel: a workgroup (ppw pairs) stages them once
+    # What the kernel executes per (pair, rated entry): A x (add, max, fma) for the score (4 flop per a) + UE x fma for the
+    # aggregation (2 flop per feature) + the softmax arithmetic — the reformulated attention (AttentionNet.0 split at the cat
+    # boundary, UserEmbeddings linearity), NOT the reference's per-pair (2 IE -> A) GEMM.  Its operands come from LDS / cache
+    # (rows are staged once per workgroup), so the bound is the fp32 VECTOR issue rate: 157.3 TFLOP/s (= the fp32 MFMA figure).
+    flop_per_pair = nnz * (4 * A + 2 * UE + 8)
+    tf = flop_per_pair * B / (us * 1e-6) / 1e12
     bytes_per_pair_pp = nnz * (A * 4 + UE * 4 + 4 + 4 + 3 * 4)   # pr row + projected row + col + val + weights r/w
     bytes_per_pair_g = nnz * (A * 4 + UE * 4 + 4 + 4) / ppw + A * 4 + UE * 4 + 8
-    flop_per_pair = nnz * (3 * A + 2 * UE + 8)                 # add, relu, fma per (entry, a); fma per (entry, f); softmax
-    gbs = B * (bytes_per_pair_pp if per_pair else bytes_per_pair_g) / (us * 1e-6) / 1e9
+    bpp = bytes_per_pair_pp if per_pair else bytes_per_pair_g
+    dig = bench.profile_digest("ncf::attn_kernel" if per_pair else "ncf::attn_grouped", "cfg3") or {}
     line = {"metric": "AttentionNCF scored pairs/sec", "value": B * args.steps / wall, "unit": "pairs/s", "n_gpus": 1,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "steps": args.steps, "warmup": warm, "warmup_requested": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg3: AttentionNCF, catalogue {I}, {nnz} rated/user, IE=UE={IE}, A={A}, F={Fdim}, B={B} "
                                    f"(64 users per batch, pairs in random user order; "
                                    f"{'one CSR row per pair: per-pair kernel' if per_pair else 'one CSR row per user + pair_row: LDS-tiled grouped kernel'}); "
@@ -225,18 +303,20 @@ def run_cfg3(args, device):
                                       else "step enqueued kernel by kernel from Python"),
                        "reference_formulation_mfma_bound_pairs_per_s": 157.3e12 / (nnz * (2 * 2 * IE * A + 2 * A) + 2 * (128 * 256 + 256 * 128 + 128)),
                        "eager_ms_per_step": wall_eager / args.steps * 1e3, "eager_pairs_per_s": B * args.steps / wall_eager,
-                       "graph_replay_ms_per_step": None if graph_err or os.environ.get("NCF_CFG3_NO_GRAPH") == "1" else wall_graph / args.steps * 1e3,
+                       "graph_replay_ms_per_step": None if wall_graph is None else wall_graph / args.steps * 1e3,
                        "graph_error": graph_err},
-            "roofline": {"kernel": "attn_kernel<0>" if per_pair else "attn_grouped_kernel<0>", "bound": "hbm", "achieved": gbs,
-                         "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None, "us_per_launch": us,
-                         "algorithmic_bytes_per_pair": bytes_per_pair_pp if per_pair else bytes_per_pair_g,
-                         "algorithmic_flop_per_pair": flop_per_pair,
-                         "valu_TFLOPs_at_this_rate": flop_per_pair * B / (us * 1e-6) / 1e12,
+            "roofline": {"kernel": "attn_kernel<0>" if per_pair else "attn_grouped_kernel<0>", "bound": "valu", "achieved": tf,
+                         "peak": bench.PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / bench.PEAK_F32_MFMA_TFLOPS,
+                         "traffic": dig.get("traffic"), "us_per_launch": us, "us_back_to_back": us_g_b2b,
+                         "algorithmic_flop_per_pair": flop_per_pair, "algorithmic_bytes_per_pair": bpp,
+                         "algorithmic_bytes_per_launch": bpp * B, "hbm_GBps_at_this_rate": bpp * B / (us * 1e-6) / 1e9,
                          "per_pair_kernel_us": us_pp, "grouped_kernel_us": us_g, "grouping_prep_us": us_group_prep,
                          "pairs_per_workgroup": ppw, "candidate_linear_us": lin_us,
-                         "note": "the grouped kernel is VALU / LDS bound (its tiles come from L2 / the Infinity Cache once per "
-                                 "workgroup): the byte rate is what it needs, not what limits it; the per-pair kernel's tables "
-                                 "(51 MB + 26 MB) are cache resident: gathered cache bandwidth, HBM peak is the reference line"}}
+                         "rocprof_avg_us": dig.get("rocprof_avg_us"), "profile": dig.get("profile"),
+                         "note": "bound = fp32 vector (VALU) issue: the contract's hbm/mfma pair does not describe this kernel — its tiles come "
+                                 "from L2 / the Infinity Cache once per workgroup (hbm_GBps_at_this_rate is what it NEEDS, a few % of HBM), "
+                                 "and relu sits between the add and the dot, so the matrix cores cannot take the (pair, entry, a) loop; "
+                                 "peak = 157.3 TFLOP/s fp32 vector = the fp32 MFMA figure"}}
     if not getattr(args, "no_cpu_baseline", False):
         # CPU oracle, reference formulation (materialised candidate x rated pairs, attention_ncf.py:154-213) on a down-scaled
         # sample: 64 pairs of 16 users against those users' own rated items (the full 4096 x 100k pair grid is 2·B·I·IE floats)
@@ -257,20 +337,46 @@ def run_cfg3(args, device):
         line["cpu_baseline"] = {"value": 64 / sec, "unit": "pairs/s", "cores": cores, "kind": "port",
                                 "sample": f"reference formulation on 64 pairs of {users} users x {nnz} rated against their {int(rated_ids.numel())} rated items, "
                                           f"median of 20 forwards after 5 warm-ups ({sec * 1e3:.0f} ms each), torch CPU fp32"}
-    print(json.dumps(line), flush=True)
+    return line
 
 
-def run_cfg5(args, device):
+# ---------------------------------------------------------------------------------------------------- cfg 5
+def _cfg5_cpu_baseline(ws, bs, E, B):
+    """CPU oracle, table formulation with bf16 operands (oracle.basic_ncf_forward_indexed_bf16's arithmetic) on down-scaled
+    tables (4 M users x 1 M items: the CPU rate does not depend on the table height once it is far beyond the caches)."""
+    from oracle import ncf_oracle as O
+    Uc, Ic = 4_000_000, 1_000_000
+    g = torch.Generator().manual_seed(5)
+    tu = (torch.randn(Uc, E, generator=g) * 0.05).to(torch.bfloat16)
+    ti = (torch.randn(Ic, E, generator=g) * 0.05).to(torch.bfloat16)
+    layers = [(w.detach().cpu().to(torch.bfloat16).float() if k < len(ws) - 1 else w.detach().cpu().float(), b.detach().cpu().float())
+              for k, (w, b) in enumerate(zip(ws, bs))]
+    iu = torch.randint(0, Uc, (B,), generator=g)
+    ii = torch.randint(0, Ic, (B,), generator=g)
+
+    def step():
+        x = torch.cat((tu[iu], ti[ii]), dim=1).float()
+        h = torch.relu(torch.nn.functional.linear(x, *layers[0])).to(torch.bfloat16).float()   # hidden layer 1 re-rounded to bf16
+        h = torch.relu(torch.nn.functional.linear(h, *layers[1]))
+        return torch.nn.functional.linear(h, *layers[2])
+
+    with torch.no_grad():
+        sec, cores = _cpu_median_s(step, reps=20, warm=3)
+    return {"value": B / sec, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"table formulation, bf16 tables {Uc} x {E} / {Ic} x {E} (down-scaled from 100 M / 10 M rows) and bf16-rounded weights, "
+                      f"fp32 accumulate, batch {B}, median of 20 after 3 warm-ups ({sec * 1e3:.0f} ms each), torch CPU"}
+
+
+def run_cfg5(args, ctx):
     """BASELINE config 5: BasicNCF, 100 M users x 10 M items, emb 128 bf16, tables row-sharded over the ranks with
     all-to-all (RCCL) exchange; local batch 65 536 per rank (weak scaling).  At world size 1 there is no exchange."""
-    import torch.distributed as dist
+    import bench
     from deeprecommendation_amd import native
-    from deeprecommendation_amd.sharded import RowShardedTable, ShardedBasicNCF
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    from deeprecommendation_amd.sharded import ExchangeOverflow, RowShardedTable, ShardedBasicNCF
+    device, world, rank = ctx.device, ctx.world, ctx.rank
     U, I, E, B = 100_000_000, 10_000_000, 128, 65_536
+    if os.environ.get("NCF_CFG5_SMALL") == "1":      # rehearsals on a shared GPU: 1/50 of the rows
+        U, I = 2_000_000, 200_000
     strong = os.environ.get("NCF_CFG5_STRONG") == "1"   # fixed global batch of 65 536 pairs (SURVEY 8d cfg 5, second form)
     if strong:
         B = B // world
@@ -290,80 +396,115 @@ def run_cfg5(args, device):
     dims = [2 * E, 256, 128, 1]
     ws = [(torch.rand((dims[k + 1], dims[k]), device=device, generator=gw) * 2 - 1) / dims[k] ** 0.5 for k in range(3)]
     bs = [(torch.rand((dims[k + 1],), device=device, generator=gw) * 2 - 1) / dims[k] ** 0.5 for k in range(3)]
-    model = ShardedBasicNCF(tu, U, ti, I, ws, bs, replicate_items=replicate, dtype=torch.bfloat16)
     gi = torch.Generator(device=device).manual_seed(2024 + rank)
     batches = [(torch.randint(0, U, (B,), device=device, generator=gi), torch.randint(0, I, (B,), device=device, generator=gi))
                for _ in range(8)]
+    nb = len(batches)
+    forms = {}
 
-    def step(k):
-        iu, ii = batches[k % 8]
-        return model(iu, ii)
+    def timed(model, pipelined):
+        if pipelined:
+            state = {"t": None}
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            def step(k):   # the exchange of step k+1 is enqueued before step k is scored
+                if state["t"] is None:
+                    state["t"] = model.submit(*batches[k % nb])
+                nxt = model.submit(*batches[(k + 1) % nb])
+                out = model.score(state["t"])
+                state["t"] = nxt
+                return out
+        else:
+            def step(k):
+                return model(*batches[k % nb])
+        wall, warm = _time_steps(step, args.warmup, args.steps, ctx)
+        if pipelined and state["t"] is not None:
+            model.score(state["t"])        # drain the last submitted exchange
+        return ctx.max_over_ranks(wall), warm
 
-    for k in range(args.warmup):
-        step(k)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    barrier()
-    wall = time.perf_counter() - t0
+    model = ShardedBasicNCF(tu, U, ti, I, ws, bs, replicate_items=replicate, dtype=torch.bfloat16, exchange="bounded")
+    caps = None
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    # dominant kernel at this rank: the bf16 fused kernel on an already-exchanged batch
-    urows, uinv = model.users.lookup_unique(batches[0][0])
-    irows, iinv = (model.items_full, batches[0][1]) if replicate else model.items.lookup_unique(batches[0][1])
+        caps = model.negotiate_capacity(*batches[0])     # the ONE host read of the bounded exchange
+    wall, warm = timed(model, pipelined=world > 1)
+    overflow = False
+    try:
+        model.check()
+    except ExchangeOverflow:
+        overflow = True
+    forms["bounded_pipelined" if world > 1 else "single_gpu"] = {"ms_per_step": wall / args.steps * 1e3, "pairs_per_s": world * B * args.steps / wall,
+                                                                  "capacity": caps, "overflow": overflow}
+    main_wall, main_warm = wall, warm
+    if world > 1:
+        for name, kw, pipe in (("bounded_serial", {"exchange": "bounded"}, False), ("unique_dedup_host_sizes", {"exchange": "unique"}, False)):
+            try:
+                m2 = ShardedBasicNCF(tu, U, ti, I, ws, bs, replicate_items=replicate, dtype=torch.bfloat16, **kw)
+                if kw["exchange"] == "bounded":
+                    m2.negotiate_capacity(*batches[0])
+                w2, _ = timed(m2, pipelined=pipe)
+                forms[name] = {"ms_per_step": w2 / args.steps * 1e3, "pairs_per_s": world * B * args.steps / w2}
+                if kw["exchange"] == "unique":
+                    forms[name]["exchange_stats_rank0"] = m2.users.last_stats
+                del m2
+            except Exception as exc:  # noqa: BLE001 — a side-by-side form must not cost the main one
+                forms[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        best = min((f for f in forms if "ms_per_step" in forms[f]), key=lambda f: forms[f]["ms_per_step"])
+        main_wall = forms[best]["ms_per_step"] * 1e-3 * args.steps
+    # dominant kernel at this rank: the bf16 fused kernel straight off this rank's shards (random local rows from HBM)
+    gl = torch.Generator(device=device).manual_seed(77 + rank)
+    lu = torch.randint(0, tu.shape[0], (B,), device=device, generator=gl)
+    li = torch.randint(0, ti.shape[0], (B,), device=device, generator=gl)
     out = torch.empty((B, 1), device=device)
-    us = _per_launch_us(lambda: native.score_fused(urows, uinv, irows, iinv, model.packed, out=out), reps=100)
+    us = bench.isolated_us(lambda: native.score_fused(tu, lu, ti, li, model.packed, out=out), reps=100, settle=60)
+    us_b2b = bench.back_to_back_us(lambda: native.score_fused(tu, lu, ti, li, model.packed, out=out), reps=100, settle=60)
     flop = 2 * (256 * 256 + 256 * 128 + 128)
     tf = flop * B / (us * 1e-6) / 1e12
-    # the same kernel (weight-stationary persistent) on a 16x larger local batch straight off this rank's shards (random
-    # local rows from HBM)
+    # the same kernel on a 16x larger local batch (north_star: ">= 50 % MFMA utilisation on the MLP at emb_dim = 128")
     BL = 16 * B
-    gl = torch.Generator(device=device).manual_seed(77 + rank)
-    lu = torch.randint(0, tu.shape[0], (BL,), device=device, generator=gl)
-    li = torch.randint(0, ti.shape[0], (BL,), device=device, generator=gl)
+    lu2 = torch.randint(0, tu.shape[0], (BL,), device=device, generator=gl)
+    li2 = torch.randint(0, ti.shape[0], (BL,), device=device, generator=gl)
     outl = torch.empty((BL, 1), device=device)
-    usl = _per_launch_us(lambda: native.score_fused(tu, lu, ti, li, model.packed, out=outl), reps=30)
+    usl = bench.isolated_us(lambda: native.score_fused(tu, lu2, ti, li2, model.packed, out=outl), reps=30, settle=10)
     tfl = flop * BL / (usl * 1e-6) / 1e12
-    if rank == 0:
-        line = {"metric": "scored user-item pairs/sec", "value": world * B * args.steps / wall, "unit": "pairs/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-                "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": f"cfg5: BasicNCF {U} users x {I} items, emb_dim={E} bf16, local batch {B}, MLP 256-256-128-1, "
-                                       f"user table row-sharded x{world}, item table {'replicated' if replicate else 'row-sharded'}, "
-                                       "unique-id dedup before the all-to-all",
-                           "exchange_stats_rank0": model.users.last_stats},
-                "roofline": {"kernel": "score_ws_bf16_kernel<256,256,128>", "bound": "mfma", "achieved": tf, "peak": 2500.0,
-                             "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None, "us_per_launch": us,
-                             "algorithmic_flop_per_pair": flop, "algorithmic_bytes_per_pair": 532,
-                             "hbm_GBps_at_this_rate": 532 * B / (us * 1e-6) / 1e9},
-                "variants": {"local_batch_1048576_weight_stationary_kernel": {
-                    "kernel": "score_ws_bf16_kernel<256,256,128>", "us_per_launch": usl, "pairs_per_s": BL / (usl * 1e-6),
-                    "achieved_TFLOPs": tfl, "frac_of_bf16_mfma_peak": tfl / 2500.0, "hbm_GBps_at_this_rate": 532 * BL / (usl * 1e-6) / 1e9}}}
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    dig = bench.profile_digest("ncf::score_ws_bf16_kernel", "cfg5") or {}
+    line = {"metric": "scored user-item pairs/sec", "value": world * B * args.steps / main_wall, "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": main_warm, "warmup_requested": args.warmup, "ms_per_step": main_wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"cfg5: BasicNCF {U} users x {I} items, emb_dim={E} bf16, local batch {B}, MLP 256-256-128-1, "
+                                   f"user table row-sharded x{world}, item table {'replicated' if replicate else 'row-sharded'}",
+                       "exchange": "none (both tables on the one GPU)" if world == 1 else
+                                   "device-side owner bucketing into fixed-capacity buffers, equal-split all-to-alls, step t+1's exchange "
+                                   "on a second stream under step t's MLP; value = the fastest form below"},
+            "exchange_forms": forms,
+            "roofline": {"kernel": "score_ws_bf16_kernel<256,256,128>", "bound": "mfma", "achieved": tf, "peak": bench.PEAK_BF16_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf / bench.PEAK_BF16_MFMA_TFLOPS, "traffic": dig.get("traffic"), "us_per_launch": us,
+                         "us_back_to_back": us_b2b, "algorithmic_flop_per_pair": flop, "algorithmic_bytes_per_pair": 532,
+                         "algorithmic_bytes_per_launch": 532 * B, "hbm_GBps_at_this_rate": 532 * B / (us * 1e-6) / 1e9,
+                         "rocprof_avg_us": dig.get("rocprof_avg_us"), "profile": dig.get("profile")},
+            "variants": {"local_batch_1048576": {
+                "kernel": "score_ws_bf16_kernel<256,256,128>", "us_per_launch": usl, "pairs_per_s": BL / (usl * 1e-6),
+                "achieved_TFLOPs": tfl, "frac_of_bf16_mfma_peak": tfl / bench.PEAK_BF16_MFMA_TFLOPS,
+                "hbm_GBps_at_this_rate": 532 * BL / (usl * 1e-6) / 1e9}}}
+    if world == 1 and not getattr(args, "no_cpu_baseline", False):
+        line["cpu_baseline"] = _cfg5_cpu_baseline(ws, bs, E, B)
+    return line
 
 
-def run_train2(args, device):
+# ---------------------------------------------------------------------------------------------------- train2
+def run_train2(args, ctx):
     """Training step on the cfg-2 shape: BasicNCF 1 M x 100 k, emb 64, batch 65 536, MLP [256,128],
     dropout 0.2, MSE-sum loss, Adam over every parameter (the reference's optimiser, train.py:55).  Forward + backward
     of the gather and Linear(+ReLU) layers on the HIP autograd blocks, next to the same step with plain torch ops
     (rocBLAS / ATen) on the same GPU.  Unit: trained pairs/s."""
     import bench
     from deeprecommendation_amd.optim import FusedAdam
+    device = ctx.device
     res = {}
     modes = ("hip_blocks_fused_adam", "hip_blocks", "torch_ops", "torch_ops_fused_adam")
     if os.environ.get("NCF_TRAIN2_ONLY"):
         modes = (os.environ["NCF_TRAIN2_ONLY"],)
+    warm = 0
     for mode in modes:
         model = bench.make_model(device).train()
         model.train_with_torch_ops = mode.startswith("torch_ops")
@@ -388,13 +529,13 @@ def run_train2(args, device):
             loss.backward()
             opt.step()
 
-        wall, _ = _time_steps(step, args.warmup, args.steps)
+        wall, warm = _time_steps(step, args.warmup, args.steps)
         res[mode] = wall / args.steps
         del model, opt
         torch.cuda.empty_cache()
     best = res.get("hip_blocks_fused_adam") or next(iter(res.values()))
-    line = {"metric": "trained user-item pairs/sec (forward + backward + Adam)", "value": bench.B / best, "unit": "pairs/s",
-            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": best * 1e3, "higher_is_better": True,
+    return {"metric": "trained user-item pairs/sec (forward + backward + Adam)", "value": bench.B / best, "unit": "pairs/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": warm, "warmup_requested": args.warmup, "ms_per_step": best * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "train2: BasicNCF 1M x 100k, emb 64, batch 65536, MLP 128-256-128-1, dropout 0.2, MSE, Adam (dense)",
                        "step": "HIP blocks (column gather / scatter, Linear + ReLU fwd / dgrad / wgrad / bias grad) + FusedAdam (ncf_adam_step)",
@@ -404,25 +545,7 @@ def run_train2(args, device):
                        "note": "both ways the step is dominated by dense full-table work (dense table gradients + dense Adam over 71 M "
                                "parameters, ~2.5 ms), which the reference's Linear-layout embeddings imply; the HIP blocks cover the MLP "
                                "forward / dgrad / wgrad / bias-grad / ReLU mask"}}
-    print(json.dumps(line), flush=True)
 
 
-def main(args):
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(device)
-    if args.workload == "train2":
-        if args.steps == 400:
-            args.steps, args.warmup = 20, 3
-        return run_train2(args, device)
-    if args.workload == "cfg5":
-        if args.steps == 400:
-            args.steps, args.warmup = 100, 10
-        return run_cfg5(args, device)
-    if args.workload == "cfg4":
-        if args.steps == 400:
-            args.steps, args.warmup = 5, 1
-        run_cfg4(args, device)
-    else:
-        if args.steps == 400:
-            args.steps, args.warmup = 50, 5
-        run_cfg3(args, device)
+# name -> (function, (default steps, default warm-up))
+WORKLOADS = {"cfg3": (run_cfg3, (50, 5)), "cfg4": (run_cfg4, (5, 1)), "cfg5": (run_cfg5, (100, 10)), "train2": (run_train2, (20, 3))}

@@ -391,7 +391,7 @@ template <int NT>
 static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                          int64_t M, int K, bool relu, hipStream_t s) {
     const int64_t tiles = (M + 31) / 32;
-    const char* force = getenv("NCF_LINEAR_KERNEL");      // "rs" / "rsp": A/B and tests; unset: by shape
+    const int force = option(NCF_OPT_LINEAR_KERNEL);      // 1 = rs / 2 = rsp: A/B and tests (ncf_set_option); 0: by shape
     // persistent row-streaming form: tall problems with K a multiple of 64 (bit-identical to the one-tile-per-wave form)
     // Measured against the one-tile-per-wave form over the shapes of the hot path (tools/ab_linear.py, rs -> rsp):
     // 1.1 M x 128 x 128 584 -> 488 us; 200 000 x 128 x 128 107 -> 95; 65 536 x 128 -> 256 83 -> 59, x 256 -> 128 74 -> 54,
@@ -400,7 +400,7 @@ static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ld
     // deep-and-short problems (8192 x 256 -> 128: 18.7 vs 26.0 us; the 4096 x 2094 candidate Linear).
     // Short K (<= 128) from 128 tiles: 4096 x 64 -> 128 18.3 -> 14.4 us, -> 256 28.1 -> 17.7, 16 384 x 64 -> 128 35.0 -> 14.4
     // (splitting a K of 8 or 16 steps over 4 waves only adds the LDS reduction).
-    if (K % 64 == 0 && (force ? !strcmp(force, "rsp") : (tiles >= 512 || (K <= 128 && tiles >= 128))))
+    if (K % 64 == 0 && (force ? force == 2 : (tiles >= 512 || (K <= 128 && tiles >= 128))))
         return launch_rsp<NT>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s);
     if constexpr (NT <= 4) {
         // Skinny and deep (the 4096 x 2094 -> 64 candidate Linear of AttentionNCF: 128 row tiles): one 32-column block
@@ -409,9 +409,9 @@ static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ld
         if (NT > 1 && tiles * NT <= 512 && K >= 512) {
             // ... and with at most one such workgroup per CU, 8 K-slices (512 threads, two waves per SIMD) instead of 4:
             // 4096 x 2094 -> 64: 36.5 -> 29.9 us, 2048 rows 27.1 -> 26.0; NOT beyond 256 workgroups (8192 rows: 48.8 -> 61.0,
-            // N = 128: 47.2 -> 55.5) and 16 slices lose everywhere (tools/ab_linear_env.py, NCF_LINEAR_KS=4|8 forces one)
-            const char* ksf = getenv("NCF_LINEAR_KS");
-            const bool ks8 = ksf ? atoi(ksf) == 8 : (tiles * NT <= 256 && K >= 1024);
+            // N = 128: 47.2 -> 55.5) and 16 slices lose everywhere (tools/ab_linear_env.py, ncf_set_option("linear_kslices", 4|8) forces one)
+            const int ksf = option(NCF_OPT_LINEAR_KSLICES);
+            const bool ks8 = ksf ? ksf == 8 : (tiles * NT <= 256 && K >= 1024);
             if (ks8) return launch_rs<1, 8>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s, NT);
             return launch_rs<1, 4>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s, NT);
         }

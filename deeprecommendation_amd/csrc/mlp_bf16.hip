@@ -825,17 +825,6 @@ static void launch_bf16(const Bf16Args& a, hipStream_t s) {
     hipLaunchKernelGGL((score_fused_bf16_kernel<K0, N1, N2>), dim3((unsigned)((tiles + NCF_BF16_WGW - 1) / NCF_BF16_WGW)), dim3(NCF_BF16_WGW * 64), 0, s, a);
 }
 
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
 template <int K0, int N1, int N2>
 static void launch_ws_bf16(const Bf16Args& a, const unsigned char* zeros, hipStream_t s) {
     const int64_t ntiles = (a.B + 63) / 64;
@@ -915,12 +904,9 @@ int bf16_score(const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, i
     // 512..8192 pairs 7.6-8.0 vs 13.6-14.6 us; 16 384: 8.7 vs 15.0; 32 768: 13.3 vs 16.8; 49 152: 16.6 vs 18.4; 65 536: 20.3 vs
     // 19.9 (4 M-row tables) and 20.9 vs 23.0 (100 M-row tables, config 5); 73 728: 21.9 vs 34.2 (the streaming kernel's
     // 256-pair workgroups go to a second round past one per CU); 131 072: 33.8 vs 38.9; 4 M: 833-885 vs 1044-1066.
-    // NCF_BF16_KERNEL=ws|stream in the environment overrides the choice (tests run every batch size through both).
+    // ncf_set_option("bf16_kernel", 1 = ws | 2 = stream) overrides the choice (tests run every batch size through both).
     bool ws = NCF_BF16_WS && B >= NCF_BF16_WS_MIN_PAIRS;
-    if (const char* force = getenv("NCF_BF16_KERNEL")) {
-        if (!strcmp(force, "ws")) ws = true;
-        else if (!strcmp(force, "stream")) ws = false;
-    }
+    if (const int force = option(NCF_OPT_BF16_KERNEL)) ws = force == 1;
     ws = ws && EA % 64 == 0 && EB % 64 == 0 && idxA && (EB == 0 || idxB);
     if (ws && !idxB) a.idxB = idxA;   // single table: the id DMA's table-B lanes fetch valid (unused) words
     bf16_dispatch(dims[0], dims[1], n_layers == 3 ? dims[2] : 0, &a, (const unsigned char*)(P + L.zeros), ws, s);

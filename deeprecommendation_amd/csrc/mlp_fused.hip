@@ -718,15 +718,7 @@ typedef void (*fused_fn)(FusedArgs);
 #define NCF_HYBRID_MAX_PERMILLE 850   // ... when it fills less than this share of a round (above: one more full round is cheaper)
 #endif
 
-static int fused_num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n = v;
-    }
-    return n;
-}
+static int fused_num_cus() { return num_cus(); }  // per-device cache in abi.hip
 
 template <int K0, int N1, int N2>
 static void launch_inst(const FusedArgs& a, hipStream_t s) {

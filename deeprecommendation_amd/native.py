@@ -30,6 +30,9 @@ SIGNATURES = {
     "ncf_version": (_c_int, []),
     "ncf_last_error": (ctypes.c_char_p, []),
     "ncf_build_arch": (ctypes.c_char_p, []),
+    "ncf_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
+    "ncf_get_option": (_c_int, [ctypes.c_char_p, _c_p]),
+    "ncf_bucket_ids": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "ncf_gather_concat": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int,
                                    _c_p, _c_i64, _c_p, _c_p]),
     "ncf_gather_dot": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p]),
@@ -97,7 +100,50 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         fn.argtypes = args
     if path is None:
         _lib = lib
+        _options_from_environment(lib)
     return lib
+
+
+# ncf_set_option values by name (include/ncf_abi.h); 0 / "auto" = choose by shape
+OPTION_VALUES = {
+    "bf16_kernel": {"auto": 0, "ws": 1, "stream": 2},
+    "linear_kernel": {"auto": 0, "rs": 1, "rsp": 2},
+    "linear_kslices": {"auto": 0, "4": 4, "8": 8},
+    "attn_grouped_kernel": {"auto": 0, "lds": 1, "scalar": 2},
+    "gather_kernel": {"auto": 0, "step": 1, "persistent": 2},
+}
+_ENV_OPTIONS = {"NCF_BF16_KERNEL": "bf16_kernel", "NCF_LINEAR_KERNEL": "linear_kernel", "NCF_LINEAR_KS": "linear_kslices",
+                "NCF_ATTN_GROUPED_KERNEL": "attn_grouped_kernel", "NCF_GATHER_KERNEL": "gather_kernel"}
+
+
+def set_option(name: str, value) -> None:
+    """Kernel-selection override (A/B tools, tests that drive every variant).  ``value``: the symbolic name
+    ("ws", "rsp", …, "auto") or the integer of include/ncf_abi.h.  Process-wide; "auto" / 0 restores the default."""
+    lib = load_library()
+    if isinstance(value, str):
+        try:
+            value = OPTION_VALUES[name][value]
+        except KeyError:
+            raise ValueError(f"option {name!r} has no value {value!r}") from None
+    _check(lib.ncf_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_int(0)
+    _check(load_library().ncf_get_option(name.encode(), ctypes.byref(v)))
+    return v.value
+
+
+def _options_from_environment(lib) -> None:
+    """The library never reads the environment; the dev tools' NCF_* variables are applied HERE, once, at load."""
+    for var, name in _ENV_OPTIONS.items():
+        v = os.environ.get(var)
+        if v:
+            if v not in OPTION_VALUES[name]:
+                raise ValueError(f"{var}={v!r}: expected one of {sorted(OPTION_VALUES[name])}")
+            rc = lib.ncf_set_option(name.encode(), OPTION_VALUES[name][v])
+            if rc != NCF_OK:
+                raise NativeError(rc, lib.ncf_last_error().decode())
 
 
 def _check(rc: int):
@@ -196,6 +242,23 @@ def gather_dot(tabA: torch.Tensor, idxA, tabB: torch.Tensor, idxB, B: Optional[i
     _check(lib.ncf_gather_dot(_dt(tabA), _ptr(tabA), rowsA, ldA, _ptr(tabB), rowsB, ldB, _ptr(idxA), _ptr(idxB), B, EA,
                               _ptr(out), _ptr(_oob_flag(tabA.device)), _stream(tabA)))
     return out
+
+
+def bucket_ids(idx: torch.Tensor, rows_per_rank: int, total_rows: int, world: int, cap: int, send: torch.Tensor,
+               slot: torch.Tensor, counts: torch.Tensor, overflow: torch.Tensor):
+    """Owner bucketing of a batch's ids for a row-sharded table (ncf_bucket_ids): fills ``send`` (world*cap,) int64 with
+    local row ids (unused slots 0), ``slot`` (B,) int64 with each pair's row in the exchanged buffer (-1 = dropped),
+    ``counts`` (world,) int32; sets the sticky out-of-range flag / ``overflow`` (int32 (1,)) on the device.  No host sync."""
+    lib = load_library()
+    _dev(idx, "idx")
+    idx = _idx(idx)
+    B = idx.numel()
+    if send.dtype != torch.int64 or send.numel() < world * cap or slot.dtype != torch.int64 or slot.numel() < B \
+            or counts.dtype != torch.int32 or counts.numel() < world or overflow.dtype != torch.int32:
+        raise ValueError("bucket_ids: send / slot must be int64 of world*cap / B elements, counts / overflow int32")
+    _check(lib.ncf_bucket_ids(_ptr(idx), B, int(rows_per_rank), int(total_rows), int(world), int(cap), _ptr(send), _ptr(slot),
+                              _ptr(counts), _ptr(_oob_flag(idx.device)), _ptr(overflow), _stream(idx)))
+    return send, slot, counts
 
 
 # ------------------------------------------------------------------ K2 generic

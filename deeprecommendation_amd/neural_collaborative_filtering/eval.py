@@ -119,6 +119,9 @@ def _resident_batches(res, batch_size, device):
     pinned = [[torch.empty(chunk, dtype=t.dtype).pin_memory() for t in host] for _ in range(sets)]
     devbuf = [[torch.empty(chunk, dtype=t.dtype, device=device) for t in host] for _ in range(sets)]
     copied, consumed = [None] * sets, [None] * sets
+    # devbuf came from the caching allocator on the compute stream: its blocks may still be in use by kernels queued there
+    # (a direct eval_model call after other work) — the copy stream must not write them before those have finished
+    side.wait_stream(main)
 
     def upload(ci):
         b, c0 = ci % sets, ci * chunk

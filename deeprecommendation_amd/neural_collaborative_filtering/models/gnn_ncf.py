@@ -92,6 +92,11 @@ class PreparedGraph:
         counts = torch.bincount(torch.cat([u2i[1], i2u[1]]), minlength=N)
         if counts.numel() != N:
             raise IndexError(f"edge destination id out of range for a graph of {N} nodes")
+        # sources are range-checked here, once per graph (the SpMM kernels skip a bad source silently; PyG's
+        # x[edge_index[0]] raises IndexError in the reference, gnn_ncf.py:74-94)
+        for ei in (u2i, i2u):
+            if ei.shape[1] and (int(ei[0].min()) < 0 or int(ei[0].max()) >= N):
+                raise IndexError(f"edge source id out of range for a graph of {N} nodes")
         deg = counts.to(torch.float32)
         self.deg = deg
         c1 = native.edge_coef(u2i[0].contiguous(), u2i[1].contiguous(), graph.user2item_edge_attr, deg)

@@ -49,4 +49,7 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     raise RuntimeError("FusedAdam needs contiguous (or transposed-contiguous) parameters")
                 native.adam_step_(pv, gv, mv, vv, group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"])
+                # the kernel writes through raw pointers: tell autograd / the models' derived-tensor caches (tables, packed
+                # MLP blobs, propagated graph tables are keyed on (data_ptr, _version)) that the parameter changed
+                torch.autograd.graph.increment_version(p)
         return loss

@@ -16,7 +16,10 @@
  *   - index arrays are int64 at the ABI (the reference uses torch.long: datasets/gnn_datasets.py:28);
  *     CSR column ids are int32 (node counts < 2^31).
  *   - leading dimensions (ld*) are in ELEMENTS of the tensor's dtype.
- *   - re-entrant: no global mutable state besides the thread-local error string.
+ *   - re-entrant and thread-safe.  State held by the library, all of it listed here: the thread-local error
+ *     string; the process-wide option table written only by ncf_set_option (atomic ints, every option defaults to
+ *     0 = "choose by shape and size"; no entry point reads the environment); a per-device cache of the CU count;
+ *     and the dynamic-LDS limit of the attention kernels, raised once per kernel instantiation and device.
  *   - out-of-range indices never fault: the offending row is read as zeros and, when `dev_oob_flag` is
  *     non-NULL, *dev_oob_flag is set to 1 (the host wrapper turns that into IndexError on request, which is
  *     what torch indexing raises in the reference).
@@ -50,6 +53,18 @@ const char* ncf_last_error(void);
 /* Architecture the device code was compiled for ("gfx950"). */
 const char* ncf_build_arch(void);
 
+/* Process-wide kernel-selection overrides for A/B measurements and for tests that must drive every kernel variant
+ * (no counterpart upstream).  0 always means "choose by shape and size" (the default).  Options:
+ *   "bf16_kernel"          1 = weight-stationary persistent kernel, 2 = slab-streaming kernel   (ncf_score_fused, NCF_BF16)
+ *   "linear_kernel"        1 = one row tile per wave, 2 = persistent row-streaming form          (ncf_mlp_forward / ncf_linear_forward)
+ *   "linear_kslices"       4 | 8 = K-slices of the skinny-deep Linear form
+ *   "attn_grouped_kernel"  1 = LDS-broadcast form, 2 = scalar-operand form                       (ncf_attn_forward_grouped)
+ *   "gather_kernel"        1 = one step per wave, 2 = persistent prefetching waves                (ncf_gather_concat)
+ * Every variant of one entry computes the same function (bit-identical where the entry promises it).
+ * NCF_EINVAL for an unknown name or a value outside the option's set. */
+int ncf_set_option(const char* name, int value);
+int ncf_get_option(const char* name, int* value);
+
 /* ------------------------------------------------------------------------------------------------
  * K1  embedding gather (+ fused concat)
  * Replaces: nn.Linear applied to one-hot rows + torch.cat — models/basic_ncf.py:38-40, models/mf.py:29-30;
@@ -74,6 +89,22 @@ int ncf_gather_dot(int dtype,
                    const int64_t* dev_idxA, const int64_t* dev_idxB,
                    int64_t B, int E, float* dev_out,
                    int32_t* dev_oob_flag, ncf_stream_t stream);
+
+/* Exchange preparation for ROW-SHARDED tables (BASELINE config 5: the table outgrows one GPU; the reference is single
+ * device — its lookup is the nn.Linear on one-hot rows of models/basic_ncf.py:38-39 — so this has no upstream counterpart).
+ * Rank o of `world` owns rows [o * rows_per_rank, (o+1) * rows_per_rank) of a table of total_rows rows.  Lists the batch's
+ * ids by owner in a FIXED-capacity send buffer so that the all-to-all exchanges that follow use equal splits and need
+ * no size on the host:
+ *   dev_send[o * cap + k] = id - o * rows_per_rank   for the k-th id of owner o (k < cap; order inside a bucket unspecified);
+ *                           unused slots are 0 (a valid local row wherever the shard is not empty)
+ *   dev_slot[p]           = o * cap + k  — the row of pair p in the (world * cap)-row buffer the row exchange returns;
+ *                           -1 for an id outside [0, total_rows) (sets *dev_oob_flag) or beyond its bucket's capacity
+ *                           (sets *dev_overflow_flag): such a pair then reads as an out-of-range row downstream
+ *   dev_counts[o]         = number of ids owned by o (may exceed cap)
+ * dev_send (world * cap) and dev_counts (world) are zero-filled by this call.  world <= 1024. */
+int ncf_bucket_ids(const int64_t* dev_idx, int64_t B, int64_t rows_per_rank, int64_t total_rows, int world, int64_t cap,
+                   int64_t* dev_send, int64_t* dev_slot, int32_t* dev_counts,
+                   int32_t* dev_oob_flag, int32_t* dev_overflow_flag, ncf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K2  MLP forward, generic layer-by-layer path (any dims)

@@ -41,3 +41,18 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def kernel_option(gpu):
+    """set(name, value): ncf_set_option for the duration of one test (kernel-variant overrides; restored to "auto")."""
+    from deeprecommendation_amd import native
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        native.set_option(name, "auto" if value is None else value)
+
+    yield set_
+    for name in touched:
+        native.set_option(name, "auto")

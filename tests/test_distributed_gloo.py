@@ -21,12 +21,38 @@ class TorchOps:
     """CPU stand-ins for the HIP entry points (same argument meaning)."""
 
     @staticmethod
-    def gather_rows(table, idx):
-        return table[idx]
+    def gather_rows(table, idx, out=None):
+        if out is None:
+            return table[idx]
+        out.copy_(table[idx])
+        return out
+
+    @staticmethod
+    def bucket_ids(idx, rows_per_rank, total_rows, world, cap, send, slot, counts, overflow):
+        """ncf_bucket_ids restated with torch ops (include/ncf_abi.h): ids listed by owner, cap slots per owner."""
+        send.zero_()
+        ok = (idx >= 0) & (idx < total_rows)
+        owner = torch.where(ok, idx // rows_per_rank, torch.zeros_like(idx))
+        counts.copy_(torch.bincount(owner[ok], minlength=world).to(torch.int32))
+        order = torch.argsort(owner, stable=True)
+        start = torch.cumsum(torch.bincount(owner, minlength=world), 0) - torch.bincount(owner, minlength=world)
+        k = torch.empty_like(idx)
+        k[order] = torch.arange(idx.numel()) - start[owner[order]]
+        # (ids that are not ok were counted under owner 0 for the ranking only; they are dropped below)
+        keep = ok & (k < cap)
+        if bool((ok & (k >= cap)).any()):
+            overflow[0] = 1
+        s = torch.where(keep, owner * cap + k, torch.full_like(idx, -1))
+        send[s[keep]] = (idx - owner * rows_per_rank)[keep]
+        slot[:idx.numel()] = s
+        return send, slot, counts
 
     @staticmethod
     def score(tabA, idxA, tabB, idxB, packed, weights, biases):
-        x = torch.cat((tabA[idxA], tabB[idxB]), dim=1).float()
+        def rows(tab, idx):  # an index outside the table reads as a zero row (the kernels' out-of-range contract)
+            ok = (idx >= 0) & (idx < tab.shape[0])
+            return tab[idx.clamp(0, tab.shape[0] - 1)] * ok[:, None]
+        x = torch.cat((rows(tabA, idxA), rows(tabB, idxB)), dim=1).float()
         return O.mlp_forward(x, list(zip(weights, biases)))
 
     @staticmethod
@@ -57,8 +83,8 @@ def _init(rank, world, store_path):
     dist.init_process_group("gloo", init_method=f"file://{store_path}", rank=rank, world_size=world)
 
 
-def _sharded_worker(rank, world, store_path, replicate_items):
-    from deeprecommendation_amd.sharded import RowShardedTable, ShardedBasicNCF
+def _sharded_worker(rank, world, store_path, replicate_items, exchange="unique"):
+    from deeprecommendation_amd.sharded import ExchangeOverflow, RowShardedTable, ShardedBasicNCF
     _init(rank, world, store_path)
     try:
         g = torch.Generator().manual_seed(0)
@@ -71,8 +97,12 @@ def _sharded_worker(rank, world, store_path, replicate_items):
         ulo, uhi = RowShardedTable.shard_bounds(U, world, rank)
         ilo, ihi = RowShardedTable.shard_bounds(I, world, rank)
         model = ShardedBasicNCF(tu[ulo:uhi], U, ti if replicate_items else ti[ilo:ihi], I, ws, bs,
-                                replicate_items=replicate_items, local_ops=TorchOps)
+                                replicate_items=replicate_items, local_ops=TorchOps, exchange=exchange)
         gb = torch.Generator().manual_seed(100 + rank)
+        if exchange == "bounded":
+            model.users.set_capacity(300)      # the largest batch below is 257 ids: never overflows
+            if model.items is not None:
+                model.items.set_capacity(300)
         for case in range(4):
             B = [64, 1, 257, 40][case]
             up = torch.randint(0, U, (B,), generator=gb)
@@ -85,12 +115,49 @@ def _sharded_worker(rank, world, store_path, replicate_items):
             out = model(up, ip)
             ref = O.mlp_forward(torch.cat((tu[up], ti[ip]), 1), list(zip(ws, bs)))
             assert torch.equal(out, ref), f"rank {rank} case {case}"
-            st = model.users.last_stats
-            assert st["unique"] <= st["requested"] and st["remote_rows"] <= st["unique"]
-            if case == 3:
-                assert st["remote_rows"] == 0
+            if exchange == "unique":
+                st = model.users.last_stats
+                assert st["unique"] <= st["requested"] and st["remote_rows"] <= st["unique"]
+                if case == 3:
+                    assert st["remote_rows"] == 0
         rows = model.users.lookup(torch.tensor([0, U - 1, ulo, max(uhi - 1, 0)]))
         assert torch.equal(rows, tu[torch.tensor([0, U - 1, ulo, max(uhi - 1, 0)])])
+        if exchange == "bounded":
+            model.check()                       # nothing was dropped so far
+            # pipelined form: the exchange of batch k+1 is submitted before batch k is scored; 3 batches through 2 buffer sets
+            ups = [torch.randint(0, U, (100,), generator=gb) for _ in range(3)]
+            ips = [torch.randint(0, I, (100,), generator=gb) for _ in range(3)]
+            t = model.submit(ups[0], ips[0])
+            for k in range(3):
+                nxt = model.submit(ups[k + 1], ips[k + 1]) if k + 1 < 3 else None
+                out = model.score(t)
+                assert torch.equal(out, O.mlp_forward(torch.cat((tu[ups[k]], ti[ips[k]]), 1), list(zip(ws, bs)))), f"pipelined batch {k}"
+                t = nxt
+            model.check()
+            # capacity agreed from a sample batch: max bucket over both ranks x 1.25, a multiple of 256
+            caps = model.negotiate_capacity(ups[0], ips[0])
+            assert caps["users"] % 256 == 0 and caps["users"] >= 256
+            # a bucket beyond the capacity: the flag is raised at check(), on the rank whose bucket overflowed
+            model.users.set_capacity(8)
+            if model.items is not None:
+                model.items.set_capacity(300)
+            up = torch.full((40,), U - 1, dtype=torch.int64) if rank == 0 else torch.randint(ulo, uhi, (5,), generator=gb)
+            ip = torch.randint(0, I, (up.numel(),), generator=gb)
+            model(up, ip)
+            if rank == 0:
+                with pytest.raises(ExchangeOverflow):
+                    model.check()
+            else:
+                model.check()
+        else:
+            # an id outside the table: IndexError on the rank that asked for it, collectives stay matched
+            up = torch.tensor([0, U if rank == 0 else 1])
+            ip = torch.tensor([0, 1])
+            if rank == 0:
+                with pytest.raises(IndexError):
+                    model(up, ip)
+            else:
+                model(up, ip)
     finally:
         dist.destroy_process_group()
 
@@ -141,8 +208,20 @@ def _spawn(fn, *args):
 
 
 @pytest.mark.parametrize("replicate_items", [False, True])
-def test_row_sharded_basic_ncf_world2(replicate_items):
-    _spawn(_sharded_worker, replicate_items)
+@pytest.mark.parametrize("exchange", ["unique", "bounded"])
+def test_row_sharded_basic_ncf_world2(replicate_items, exchange):
+    _spawn(_sharded_worker, replicate_items, exchange)
+
+
+def test_partitioned_lightgcn_rejects_other_convolutions():
+    from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphData, GraphNCF
+    from deeprecommendation_amd.sharded import PartitionedLightGCN
+    ei = torch.tensor([[3, 4], [0, 1]])
+    graph = GraphData(user2item_edge_index=ei, item2user_edge_index=ei.flip(0), num_items=3, num_users=2)
+    for kw in ({"convType": "LightGAT"}, {"concat": True}):
+        model = GraphNCF(item_dim=3, user_dim=2, num_gnn_layers=1, hetero=False, node_emb=4, mlp_dense_layers=[4], **kw)
+        with pytest.raises(NotImplementedError):
+            PartitionedLightGCN(model, graph, local_ops=TorchOps)
 
 
 @pytest.mark.parametrize("mode", ["dst", "edge"])

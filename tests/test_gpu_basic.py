@@ -1,7 +1,9 @@
 """GPU parity tests (MI355X) for K1 gather, K2 MLP and the fused scoring kernel, through the C ABI.
 
-Bars: index gathers bit-exact (torch.equal); fp32 MLP within 1e-5 relative of the CPU oracle
-(|a-b| <= 1e-5 * |b| + 1e-5 * max|b|) — BASELINE.json north_star tolerance.
+Bars: index gathers bit-exact (torch.equal); fp32 MLP within 1e-5 relative of the CPU oracle — BASELINE.json
+north_star tolerance — written as |a-b| <= 1e-5 * |b| + 1e-6 * max|b|: the absolute floor (a tenth of the bar, on the
+batch's largest output) is there because scores pass through zero, and the fp32 summation-order difference between
+two correct implementations scales with sum|w·x|, not with the (cancelled) result.
 """
 import numpy as np
 import pytest
@@ -19,7 +21,7 @@ def assert_close(a, ref, rtol=RTOL):
     a = a.detach().cpu().double()
     ref = ref.detach().cpu().double()
     assert a.shape == ref.shape
-    tol = rtol * ref.abs() + rtol * ref.abs().max()
+    tol = rtol * ref.abs() + 0.1 * rtol * ref.abs().max()
     bad = (a - ref).abs() > tol
     assert not bool(bad.any()), f"max abs err {(a - ref).abs().max().item():.3e}, ref scale {ref.abs().max().item():.3e}"
 
@@ -245,7 +247,7 @@ def test_full_size_cfg2_properties(native, gpu):
     native.check_oob(gpu)
 
 
-def test_full_size_cfg5_properties(native, gpu, monkeypatch):
+def test_full_size_cfg5_properties(native, gpu, kernel_option):
     """BASELINE configs[4] at one GPU's full size (100 M x 128 and 10 M x 128 bf16 tables = 28 GB, MLP 256-256-128-1):
     size-independent properties of BOTH bf16 kernels at 65 536 and 262 144 pairs — (a) permuting the batch permutes the
     output bit-exactly, (b) extreme row ids (0, last) are read correctly, (c) the two kernels agree within the bf16
@@ -275,7 +277,7 @@ def test_full_size_cfg5_properties(native, gpu, monkeypatch):
         perm = torch.randperm(B, device=gpu, generator=g)
         outs = {}
         for kernel in ("stream", "ws"):
-            monkeypatch.setenv("NCF_BF16_KERNEL", kernel)
+            kernel_option("bf16_kernel", kernel)
             out = native.score_fused(tu, iu, ti, ii, packed)
             outp = native.score_fused(tu, iu[perm].contiguous(), ti, ii[perm].contiguous(), packed)
             assert torch.equal(outp, out[perm]), kernel
@@ -297,7 +299,7 @@ def test_full_size_cfg5_properties(native, gpu, monkeypatch):
 @pytest.mark.parametrize("E,hidden", [(128, [256, 128]), (128, [256]), (64, [256, 128]), (64, [256])])
 @pytest.mark.parametrize("B", [1, 63, 255, 256, 257, 3000, 40000, 100001, 140000])
 @pytest.mark.parametrize("kernel", ["stream", "ws", "auto"])
-def test_score_fused_bf16_vs_oracle(gpu, monkeypatch, E, hidden, B, kernel):
+def test_score_fused_bf16_vs_oracle(gpu, kernel_option, E, hidden, B, kernel):
     """bf16 tables / weights, fp32 accumulate: gathers are bit-exact on the bf16 table; the MLP is compared with the
     oracle evaluated on the same bf16-rounded operands — tolerance 2e-3 relative (builder-defined: BASELINE pins only
     fp32; the residual is fp32 accumulation order plus bf16 re-rounding of hidden activations that sit on a rounding
@@ -307,11 +309,11 @@ def test_score_fused_bf16_vs_oracle(gpu, monkeypatch, E, hidden, B, kernel):
     from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
     from deeprecommendation_amd import native
     if kernel == "auto":
-        monkeypatch.delenv("NCF_BF16_KERNEL", raising=False)
+        kernel_option("bf16_kernel", "auto")
         if B not in (3000, 140000):
             pytest.skip("auto dispatch is covered by one batch on each side of the threshold")
     else:
-        monkeypatch.setenv("NCF_BF16_KERNEL", kernel)
+        kernel_option("bf16_kernel", kernel)
     torch.manual_seed(E + len(hidden))
     U, I = 3000, 700
     m = BasicNCF(item_dim=I, user_dim=U, item_emb=E, user_emb=E, mlp_dense_layers=hidden).eval()
@@ -332,9 +334,9 @@ def test_score_fused_bf16_vs_oracle(gpu, monkeypatch, E, hidden, B, kernel):
 
 
 @pytest.mark.parametrize("kernel", ["stream", "ws"])
-def test_score_fused_bf16_exact_small_integers(native, gpu, monkeypatch, kernel):
+def test_score_fused_bf16_exact_small_integers(native, gpu, kernel_option, kernel):
     """Exact check of the packed layer-2 k permutation: small integer data is exact in bf16 x bf16 -> fp32."""
-    monkeypatch.setenv("NCF_BF16_KERNEL", kernel)
+    kernel_option("bf16_kernel", kernel)
     E = 64
     dims = [128, 256, 128, 1]
     B = 300
@@ -354,9 +356,9 @@ def test_score_fused_bf16_exact_small_integers(native, gpu, monkeypatch, kernel)
 
 
 @pytest.mark.parametrize("kernel", ["stream", "ws"])
-def test_score_fused_out_of_range_rows_read_as_zeros(native, gpu, monkeypatch, kernel):
+def test_score_fused_out_of_range_rows_read_as_zeros(native, gpu, kernel_option, kernel):
     """ABI contract: an out-of-range id never faults; that table's part of the row is zeros and the sticky flag is set."""
-    monkeypatch.setenv("NCF_BF16_KERNEL", kernel)
+    kernel_option("bf16_kernel", kernel)
     g = torch.Generator().manual_seed(0)
     E, dims = 64, [128, 256, 128, 1]
     ta = torch.randn(100, E, generator=g)
@@ -511,10 +513,10 @@ def test_ragged_last_round_split_is_bit_identical(native, gpu, B):
 
 @pytest.mark.parametrize("M,K,N,relu", [(20000, 256, 128, True), (16500, 64, 128, False), (300, 40, 64, True), (16384, 128, 256, False)])
 @pytest.mark.parametrize("kernel", ["rs", "rsp"])
-def test_linear_kernels_agree_with_float64(native, gpu, monkeypatch, M, K, N, relu, kernel):
+def test_linear_kernels_agree_with_float64(native, gpu, kernel_option, M, K, N, relu, kernel):
     """Both row-streaming GEMM forms (one tile per wave / persistent with the A ring across tiles) against a float64
     product, incl. a ragged last row block and a shape the persistent form declines (K % 64 != 0 falls back by itself)."""
-    monkeypatch.setenv("NCF_LINEAR_KERNEL", kernel)
+    kernel_option("linear_kernel", kernel)
     g = torch.Generator().manual_seed(M + K)
     x = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / K ** 0.5
@@ -528,14 +530,14 @@ def test_linear_kernels_agree_with_float64(native, gpu, monkeypatch, M, K, N, re
 
 @pytest.mark.parametrize("M,K,N", [(4096, 2094, 64), (1000, 2094, 64), (4100, 1030, 128), (33, 2094, 64)])
 @pytest.mark.parametrize("ks", ["4", "8", None])
-def test_skinny_split_k_widths_agree_with_float64(native, gpu, monkeypatch, M, K, N, ks):
+def test_skinny_split_k_widths_agree_with_float64(native, gpu, kernel_option, M, K, N, ks):
     """Skinny-deep Linear (AttentionNCF's F = 2094 candidate layer): K split over 4 or 8 waves of a workgroup, partial
     sums added through LDS in slice order; forced either way and by the shape rule, against a float64 product (K % 8 != 0
     tail, ragged last row block)."""
     if ks is None:
-        monkeypatch.delenv("NCF_LINEAR_KS", raising=False)
+        kernel_option("linear_kslices", "auto")
     else:
-        monkeypatch.setenv("NCF_LINEAR_KS", ks)
+        kernel_option("linear_kslices", ks)
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / K ** 0.5
