@@ -267,14 +267,14 @@ def run_cfg3(args, ctx):
         bias_u = model.UserEmbeddings[0].bias.detach()
         rs = batches[0][1] if not per_pair else None
         rx = r.expanded()
-        us_pp = bench.isolated_us(lambda: native.attn_forward(native.ATT_MLP, pc, pr, w1, b1, rx.rowptr, rx.col, rx.val, proj, out_bias=bias_u), reps=50, settle=10)
+        us_pp = bench.isolated_us(lambda: native.attn_forward(native.ATT_MLP_SCALED, pc, pr, w1, b1, rx.rowptr, rx.col, rx.val, proj, out_bias=bias_u), reps=50, settle=10)
         ppw = native.default_pairs_per_wg(B)
         us_g = us_g_b2b = us_group_prep = None
         if not per_pair:
             grouping = (native.group_pairs(rs.pair_row, rs.rowptr.numel() - 1, ppw), ppw)
 
             def grouped():
-                return native.attn_forward_grouped(native.ATT_MLP, pc, pr, w1, b1, rs.rowptr, rs.col, rs.val, rs.pair_row, proj, out_bias=bias_u,
+                return native.attn_forward_grouped(native.ATT_MLP_SCALED, pc, pr, w1, b1, rs.rowptr, rs.col, rs.val, rs.pair_row, proj, out_bias=bias_u,
                                                    grouping=grouping)
 
             us_g = bench.isolated_us(grouped, reps=50, settle=20)

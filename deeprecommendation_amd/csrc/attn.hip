@@ -13,6 +13,7 @@
 // kernel is bound by gathered cache bandwidth, not by arithmetic.
 #include "ncf_common.h"
 #include <math.h>
+#include <atomic>
 #include <type_traits>
 
 #ifndef ATT_UNROLL
@@ -49,6 +50,49 @@ __device__ __forceinline__ float wave_reduce_dpp(float v, Op op) {
     const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 31));
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 63));
     return op(op(r0, r1), op(r2, r3));
+}
+
+// The same reduction for N values at once: every DPP stage is applied to all of them before the next one, so the N
+// dependency chains interleave in the instruction stream.  Results are wave-uniform.
+template <int N, typename Op>
+__device__ __forceinline__ void wave_reduce_dpp_n(float (&v)[N], Op op) {
+    auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = op(v[i], dpp(v[i], std::integral_constant<int, 0xB1>{}));
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = op(v[i], dpp(v[i], std::integral_constant<int, 0x4E>{}));
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = op(v[i], dpp(v[i], std::integral_constant<int, 0x141>{}));
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = op(v[i], dpp(v[i], std::integral_constant<int, 0x140>{}));
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int b = __float_as_int(v[i]);
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 31));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 63));
+        v[i] = op(op(r0, r1), op(r2, r3));
+    }
+}
+
+// e^x for x <= 0 (softmax arguments; x = -inf gives 0): x log2(e) as an exact product hi + lo, 2^hi on the hardware
+// exponential, the low part as a first-order factor — about 2 ulp, 9 instructions, no range reduction (a result below the
+// normal range may flush to 0, which for a softmax term next to a term of 1 is 0 anyway).
+__device__ __forceinline__ float exp_le0(float x) {
+    const float hi = x * 1.44269504088896341f;
+    const float lo = fmaf(x, 1.44269504088896341f, -hi) + x * 1.92596299112661746e-8f;
+    const float r = __builtin_amdgcn_exp2f(hi);
+    return x == -INFINITY ? 0.f : fmaf(r, lo * 0.693147180559945309f, r);
+}
+
+// LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land contiguously from the wave-uniform LDS byte address in M0, each
+// lane fetching from ITS OWN global address).  Inline asm: M0 is saved and restored inside the statement; completion is
+// counted by hand (s_waitcnt vmcnt) before the barrier that precedes the reads.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
 }
 
 // MODE 0: MLP (relu + w1 dot), 1: linear (A == 1, pc + pr), 2: cosine (dot of normalised rows)
@@ -467,6 +511,370 @@ __global__ __launch_bounds__(512, ATT_G_WAVES_PER_SIMD) void attn_grouped_kernel
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K3 grouped, scalar-operand form (round 2).  Same contract as attn_grouped_kernel; what changed is where the operands
+// of the (pair, entry, a) loop live and which unit does what.  In the first form every lane re-read pc[b, 4c..] of its
+// wave's pairs and w1[4c..] from LDS on every step: 5 of 6 `ds_read_b128` per step were wave-uniform broadcasts and the
+// CU's LDS port, not the VALU, was saturated.  Here
+//   * pc rows and w1 are WAVE-UNIFORM: they are read straight from global memory through the scalar cache
+//     (`s_load_dwordx8` -> SGPR pairs) and enter the packed VALU ops as scalar operands — no LDS, no VGPRs;
+//   * a lane (= one entry of the 64-entry tile) reads ITS row of the staged pr tile into registers ONCE per tile (and
+//     a-block of CPB 16-byte chunks) and scores all of its wave's pairs against it: the inner loop is VALU only;
+//   * the tile is staged by LDS-DMA (`global_load_lds_dwordx4`, per-lane source address, full 1 KiB pieces; rows of
+//     A % 64 == 0 floats are XOR-swizzled on the SOURCE chunk so that the row reads are conflict-free).  Because the rows
+//     move to registers first, the pr image is free again as soon as every wave has read it: the next tile's DMA is issued
+//     THEN and lands under this tile's arithmetic — one image of each kind, no staging VGPRs, no ds_write pass;
+//   * the rating-weighted aggregation  O[pair, f] += sum_e (p_e val_e) feat[e, f]  is a real contraction over the
+//     entries: it runs on the matrix cores (`v_mfma_f32_16x16x4_f32`, exact fp32 fmaf chains; M = the workgroup's <= 16
+//     pairs, N = 16 features per tile and wave, K = the tile's 64 entries), fed from LDS (P written once per tile, the feat
+//     tile from its DMA image) — the first form spent 64 x (readlane + fma) per pair and tile on it;
+//   * online softmax as before (running max m, per-LANE partial sums l reduced once at the end, O rescaled per tile).
+// 256-thread workgroups of up to 16 pairs (4 per wave); LDS 64 x (A + Fdim) floats + P (58 KB at config 3): two
+// workgroups per CU, each with its own barriers.
+#ifdef ATT_SC_STAMP   // diagnostic build only: per-phase shader-clock sums of wave 0 of every workgroup -> the buffer passed as wts_off
+#define ATT_STAMP(slot)                                                                                 \
+    do {                                                                                                \
+        unsigned long long t_;                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        stamp_sum[slot] += t_ - stamp_last;                                                             \
+        stamp_last = t_;                                                                                \
+    } while (0)
+#else
+#define ATT_STAMP(slot) do {} while (0)
+#endif
+
+template <int MODE, int CPB, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_grouped_sc_kernel(const float* __restrict__ pc, int64_t ldpc, const float* __restrict__ pr,
+                                                                 int64_t ldpr, int A, const float* __restrict__ w1, float b1,
+                                                                 const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                 const float* __restrict__ val, int64_t R, int64_t I,
+                                                                 const int64_t* __restrict__ grp_ptr, const int64_t* __restrict__ pair_ids,
+                                                                 const int64_t* __restrict__ wg_ptr, int ppw,
+                                                                 const float* __restrict__ feat, int64_t ldfeat, int Fdim,
+                                                                 const float* __restrict__ out_bias, float* __restrict__ out, int64_t ldout,
+                                                                 float* __restrict__ wts, const int64_t* __restrict__ wts_off) {
+    constexpr int EC = 64, MAXP = 4, PP = MAXP * NW, MT = PP / 16, PS = 66, MAXNT = 4;   // NW = 4 or 8 waves, 4 pairs per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int A4 = A / 4, F4 = Fdim / 4;
+    float* prt = reinterpret_cast<float*>(smem);           // [EC][A]     pr tile image (DMA)
+    float* fct = prt + EC * A;                              // [EC][Fdim]  feat tile image (DMA)
+    float* Pm = fct + EC * Fdim;                            // [PP][PS]    p_e * val_e of the current tile, pair-major
+    float* scl = Pm + PP * PS;                              // [PP]        this tile's rescale factor per pair; at the end 1 / l
+    int64_t* pid = reinterpret_cast<int64_t*>(scl + PP);    // [PP]        output row of each pair of the group
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t g = blockIdx.x;
+    if (g >= wg_ptr[R]) return;                            // the grid is an upper bound (no host sync for its size)
+    int64_t lo = 0, hi = R;                                // row r with wg_ptr[r] <= g < wg_ptr[r+1]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (wg_ptr[mid] <= g) lo = mid; else hi = mid;
+    }
+    const int64_t r = lo;
+    const int64_t start = grp_ptr[r] + (g - wg_ptr[r]) * ppw;
+    const int64_t left = grp_ptr[r + 1] - start;
+    const int cnt = (int)(left < ppw ? left : ppw);
+    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+
+    // LDS starts as zeros: slots of pairs / entries that nothing writes then hold finite values (0 x garbage must not
+    // make a NaN in the MFMA of a VALID pair; rows of unused pairs are never stored)
+    {
+        const int total4 = (EC * (A + Fdim) + PP * PS + PP + 2 * PP) / 4;
+        for (int i = tid; i < total4; i += (int)blockDim.x) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // DMA pieces of one tile: the pr image is EC*A4 chunks = A4 wave-instructions, the feat image F4; wave w issues pieces
+    // w, w+4, ...  A piece's lane writes chunk `j` of entry `e` of the image and fetches SOURCE chunk j ^ (e & 15) of
+    // that row when rows are whole 256-byte bank rows (A % 64 == 0): the reader applies the same XOR.
+    const bool swz = (A4 % 16) == 0;
+    const int shA = (A4 & (A4 - 1)) == 0 ? __builtin_ctz(A4) : -1, shF = (F4 & (F4 - 1)) == 0 ? __builtin_ctz(F4) : -1;
+    // the tile's own entry of this lane: column and rating, loaded two tiles ahead of their use — unconditionally (index
+    // clamped into the row) and back to back: a dependent load would need a vmcnt wait, and every vmcnt wait also drains the
+    // tile DMAs in flight.  Validity (inside the row, column inside the catalogue) is decided when the values are used.
+    auto load_cv = [&](int64_t e0, int& c, float& v) {
+        const int64_t e = e0 + lane < end ? e0 + lane : (end > beg ? end - 1 : beg);
+        c = end > beg ? col[e] : -1;
+        v = end > beg ? val[e] : 0.f;
+    };
+    auto valid_c = [&](int64_t e0, int c) { return (e0 + lane < end && c >= 0 && c < I) ? c : -1; };
+    auto issue = [&](const float* tab, int64_t ld, int X4, int shX, bool xorj, unsigned lds_base, int cols) {
+        // `cols` = this lane's col of the tile being fetched (or -1).  A piece (one wave-instruction, 64 chunks) covers
+        // RPP = 64 / X4 whole rows when rows are a power of two of chunks: the row's col then comes from 1 / 2 / 4 readlanes
+        // (no LDS round trip, nothing to wait for) and every piece costs a dozen instructions.
+        const int rpp = shX >= 0 ? 64 >> shX : 0;
+        if (rpp >= 1 && rpp <= 4) {
+            const int sub = lane >> shX, j = lane & (X4 - 1);
+            for (int piece = wave; piece < X4; piece += NW) {   // wave-uniform trip count
+                const int e0p = piece * rpp;
+                int ci = __builtin_amdgcn_readlane(cols, e0p);
+                if (rpp >= 2) { const int c1 = __builtin_amdgcn_readlane(cols, e0p + 1); ci = sub == 1 ? c1 : ci; }
+                if (rpp == 4) {
+                    const int c2 = __builtin_amdgcn_readlane(cols, e0p + 2), c3 = __builtin_amdgcn_readlane(cols, e0p + 3);
+                    ci = sub == 2 ? c2 : (sub == 3 ? c3 : ci);
+                }
+                const int jj = xorj ? (j ^ ((e0p + sub) & 15)) : j;
+                if (ci >= 0) dma16(tab + (int64_t)ci * ld + 4 * jj, lds_base + (unsigned)piece * 1024u);
+            }
+            return;
+        }
+        for (int piece = wave; piece < X4; piece += NW) {  // general row widths: (entry, chunk) by division, col by a shuffle
+            const int gi = piece * 64 + lane;
+            const int e = shX >= 0 ? gi >> shX : gi / X4;
+            const int j = shX >= 0 ? gi & (X4 - 1) : gi - e * X4;
+            const int ci = __shfl(cols, e);
+            if (ci >= 0) dma16(tab + (int64_t)ci * ld + 4 * (xorj ? (j ^ (e & 15)) : j), lds_base + (unsigned)piece * 1024u);
+        }
+    };
+    auto issue_pr = [&](int cols) { issue(pr, ldpr, A4, shA, swz, lds0, cols); };
+    auto issue_feat = [&](int cols) { issue(feat, ldfeat, F4, shF, false, lds0 + (unsigned)(EC * A * 4), cols); };
+
+    // the wave's pairs: slots j = wave + NW*k; their pc rows are wave-uniform pointers (scalar loads)
+    const int np = cnt > wave ? (cnt - wave + NW - 1) / NW : 0;
+    const float* pcrow[MAXP];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int j = k < np ? wave + NW * k : 0;
+        const int64_t b = pair_ids[start + j];
+        const int blo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffff)), bhi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+        pcrow[k] = pc + (((int64_t)bhi << 32) | (unsigned)blo) * ldpc;
+#ifdef ATT_SC_SAMEROW      // diagnostic build (wrong results): every slot reads pair 0's row -> the scalar working set shrinks 4x
+        pcrow[k] = pcrow[0];
+#endif
+    }
+    if (tid < PP) pid[tid] = tid < cnt ? pair_ids[start + tid] : -1;
+
+    // MFMA roles: a job = one 16-pair x 16-feature tile of O over all 16 k-steps (4 entries each) of a tile; MT * NTILES jobs
+    const int NTILES = (Fdim + 15) / 16;
+    f32x4 acc[MAXNT];
+#pragma unroll
+    for (int i = 0; i < MAXNT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float m[MAXP], l[MAXP];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) { m[k] = -INFINITY; l[k] = 0.f; }
+
+    const int64_t ntiles = (end - beg + EC - 1) / EC;
+    int c_cur = -1, c_nxt = -1, c_nn = -1;
+    float v_cur = 0.f, v_nxt = 0.f, v_nn = 0.f;
+    __syncthreads();                                       // LDS zeroed before the first DMA lands
+    if (ntiles > 0) {
+        load_cv(beg, c_cur, v_cur);
+        load_cv(beg + EC, c_nxt, v_nxt);
+        c_cur = valid_c(beg, c_cur);
+        c_nxt = valid_c(beg + EC, c_nxt);
+        issue_pr(c_cur);
+    }
+    const int sw = swz ? (lane & 15) : 0;
+    const int g4 = lane >> 4, i16 = lane & 15;
+#ifdef ATT_SC_STAMP
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const int64_t e0 = beg + t * EC;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of pr(t) have landed (and its col / val loads) ...
+        __syncthreads();                                   // ... and everybody's; the MFMAs of tile t-1 have read fct / Pm / scl
+        if (t > 0) {                                       // rotate the look-ahead registers HERE: nothing is in flight, no wait
+            c_cur = c_nxt; v_cur = v_nxt;
+            c_nxt = valid_c(e0 + EC, c_nn); v_nxt = v_nn;
+        }
+        ATT_STAMP(0);
+        issue_feat(c_cur);                                 // lands under the scoring below (read after the third barrier)
+        load_cv(e0 + 2 * EC, c_nn, v_nn);
+        ATT_STAMP(1);
+
+        const bool ok = c_cur >= 0;
+        const float vl = ok ? v_cur : 0.f;
+        const float* myrow = prt + lane * A;
+        f32x2 s2[MAXP], t2[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) { s2[k] = f32x2{0.f, 0.f}; t2[k] = f32x2{0.f, 0.f}; }
+        for (int blk = 0; blk < A4; blk += CPB) {
+            f32x4 row[CPB];
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) row[c] = *reinterpret_cast<const f32x4*>(myrow + 4 * ((blk + c) ^ sw));
+            ATT_STAMP(2);
+            if (blk + CPB >= A4) {                         // last a-block: once every wave holds its rows the pr image is free
+                // raw barrier: __syncthreads() would wait vmcnt(0) first, i.e. for the feat DMA issued a moment ago
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's row reads have returned
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < ntiles) issue_pr(c_nxt);       // tile t+1 lands under this tile's arithmetic
+            }
+            ATT_STAMP(3);
+            // Scalar operands arrive G chunks at a time, one step ahead: a wait on scalar loads is always lgkmcnt(0)
+            // (they return out of order), so the order inside a step is  wait(step s)  ->  issue loads(step s+1)  ->
+            // VALU(step s): the next step's loads fly under this step's arithmetic, and the live scalars stay at two
+            // steps' worth (all of them at once would be 1024 SGPRs: spilled through v_writelane / v_readlane).
+            auto score_block = [&](auto slots) {
+                constexpr int NS = decltype(slots)::value;     // slots computed: 1, 2 or 4 (>= np)
+                constexpr int G = CPB >= 2 ? 2 : 1, NST = CPB / G;
+                f32x4 qs[2][NS][G], ws[2][G];
+                auto load_step = [&](int st, int slot) {
+#pragma unroll
+                    for (int gk = 0; gk < G; ++gk) {
+                        if (MODE != 2) ws[slot][gk] = *reinterpret_cast<const f32x4*>(w1 + 4 * (blk + st * G + gk));
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) qs[slot][k][gk] = *reinterpret_cast<const f32x4*>(pcrow[k] + 4 * (blk + st * G + gk));
+                    }
+                };
+                load_step(0, 0);
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const int cur = st & 1;
+                    asm volatile("" ::"s"(qs[cur][0][0][0]));   // the compiler's wait for step st sits HERE, before the next issue
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 1 < NST) load_step(st + 1, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int gk = 0; gk < G; ++gk) {
+                        const int c = st * G + gk;
+                        const f32x2 p01 = {row[c][0], row[c][1]}, p23 = {row[c][2], row[c][3]};
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) {
+                            const f32x4 q = qs[cur][k][gk];
+                            const f32x2 q01 = {q[0], q[1]}, q23 = {q[2], q[3]};
+                            if (MODE == 0 || MODE == 3) {
+                                const f32x4 ww = ws[cur][gk];
+                                const f32x2 w01 = {ww[0], ww[1]}, w23 = {ww[2], ww[3]};
+                                f32x2 u, v;
+                                if (MODE == 3) {
+                                    // operands scaled by 2^-64 (w1 by 2^64): relu(p + q) IS the [0, 1] clamp of the sum, an output
+                                    // modifier of the packed add — one instruction for two elements where gfx950 has no packed fp32
+                                    // max (2 x v_max_f32 otherwise); powers of two scale exactly: same bits as the unscaled relu
+                                    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(u) : "v"(p01), "s"(q01));
+                                    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(v) : "v"(p23), "s"(q23));
+                                } else {
+                                    u = p01 + q01, v = p23 + q23;               // v_pk_add_f32, scalar operand
+                                    u = __builtin_elementwise_max(u, (f32x2){0.f, 0.f});   // 2 x v_max_f32
+                                    v = __builtin_elementwise_max(v, (f32x2){0.f, 0.f});
+                                }
+                                s2[k] = u * w01 + s2[k];                        // v_pk_fma_f32, scalar operand
+                                t2[k] = v * w23 + t2[k];
+                            } else {
+                                s2[k] = p01 * q01 + s2[k];
+                                t2[k] = p23 * q23 + t2[k];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (np > 2) score_block(std::integral_constant<int, 4>{});
+            else if (np == 2) score_block(std::integral_constant<int, 2>{});
+            else if (np == 1) score_block(std::integral_constant<int, 1>{});
+            ATT_STAMP(4);
+        }
+        // Epilogue of the tile, the wave's pairs side by side (branch-free, so that the four dependency chains of DPP steps
+        // and exponentials interleave): tile maximum, running maximum, rescale factor, p_e.
+        float sc[MAXP], mx[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const float ssum = (s2[k][0] + t2[k][0]) + (s2[k][1] + t2[k][1]);
+            sc[k] = ok ? ssum + (MODE != 2 ? b1 : 0.f) : -INFINITY;
+            mx[k] = sc[k];
+        }
+        wave_reduce_dpp_n<MAXP>(mx, [](float x, float y) { return fmaxf(x, y); });
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const float mnew = fmaxf(m[k], mx[k]);
+            const bool any = mnew != -INFINITY;            // wave-uniform; false: nothing valid so far, m, l, O stay 0
+            const float scale = any ? exp_le0(m[k] - mnew) : 1.f;       // exp(-inf) = 0 on the first valid tile
+            const float pe = (any && ok) ? exp_le0(sc[k] - mnew) : 0.f;
+            l[k] = l[k] * scale + pe;                      // per-lane partial sum; lanes are added once, after the last tile
+            m[k] = mnew;
+            if (k < np) {                                  // wave-uniform
+                const int j = wave + NW * k;
+                if (wts && e0 + lane < end)                // raw score now, normalised in place after the last tile
+                    wts[wts_off[pid[j]] + (e0 - beg) + lane] = sc[k];
+                Pm[j * PS + lane] = pe * vl;               // attended_user_matrix entry (:212)
+                if (lane == 0) scl[j] = scale;
+            }
+        }
+        ATT_STAMP(5);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of feat(t) (and of pr(t+1)) have landed; P written
+        __builtin_amdgcn_s_barrier();                      // P, scl and the feat image of this tile are complete
+        ATT_STAMP(6);
+        {
+            // jobs: (16-pair row tile mt, 16-feature column tile nt) = (j % MT, j / MT) for j = wave, wave + NW, ...
+#pragma unroll
+            for (int n = 0; n < MAXNT; ++n) {
+                const int job = wave + NW * n;
+                const int mt = job % MT, nt = job / MT;
+                if (nt >= NTILES) break;                   // wave-uniform
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(scl + 16 * mt + 4 * g4);   // accumulator register i holds pair row 16*mt + 4*g4 + i
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[n][i] *= s4[i];
+                const float* fb = fct + 16 * nt + i16;
+                const float* pa = Pm + (16 * mt + i16) * PS + g4;
+#pragma unroll
+                for (int q0 = 0; q0 < EC / 4; q0 += 8) {    // 8 k-steps' operands first (16 LDS reads in flight), then their chain
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {           // A[i = pair][k = 4q + g4], B[k][j = feature]
+                        av[q] = pa[4 * (q0 + q)];
+                        bv[q] = fb[(4 * (q0 + q) + g4) * Fdim];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[n], 0, 0, 0);
+                }
+            }
+        }
+        ATT_STAMP(7);
+    }
+#ifdef ATT_SC_STAMP
+    if (lane == 0 && wave == 0 && !wts && wts_off) {
+        unsigned long long* dbg = (unsigned long long*)wts_off;
+        for (int i = 0; i < 8; ++i) dbg[blockIdx.x * 8 + i] = stamp_sum[i];
+    }
+#endif
+    float linv[MAXP];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        linv[k] = 0.f;
+        if (k >= np) continue;
+        const float lt = wave_reduce_dpp(l[k], [](float x, float y) { return x + y; });
+        linv[k] = lt > 0.f ? 1.0f / lt : 0.f;
+    }
+    __syncthreads();                                       // the last tile's MFMAs have read scl
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k)
+        if (k < np && lane == 0) scl[wave + NW * k] = linv[k];
+    __syncthreads();
+    {
+#pragma unroll
+        for (int n = 0; n < MAXNT; ++n) {
+            const int job = wave + NW * n;
+            const int mt = job % MT, nt = job / MT;
+            if (nt >= NTILES) break;
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(scl + 16 * mt + 4 * g4);
+            const int f = 16 * nt + i16;
+            const float bias = (out_bias && f < Fdim) ? out_bias[f] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * mt + 4 * g4 + i;
+                if (row < cnt && f < Fdim) out[pid[row] * ldout + f] = acc[n][i] * s4[i] + bias;
+            }
+        }
+    }
+    if (wts) {                                             // attention weights (:224): softmax of the stored raw scores
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            if (k >= np) continue;
+            float* wrow = wts + wts_off[pid[wave + NW * k]];    // written by this same lane pattern above
+            for (int64_t e = lane; e < end - beg; e += 64) {
+                const float sraw = wrow[e];
+                wrow[e] = (linv[k] > 0.f && sraw != -INFINITY) ? expf(sraw - m[k]) * linv[k] : 0.f;
+            }
+        }
+    }
+}
+
 // ---- pairs listed row by row for the grouped kernel (a counting sort; order inside a row is irrelevant: every pair's
 // output is computed independently) ----
 // Wave-aggregated atomics: the lanes of a wave that target the same row elect a leader which adds their count once and
@@ -666,7 +1074,8 @@ extern "C" int ncf_attn_forward(int mode, const float* pc, int64_t ldpc, const f
                                 const float* w1, float b1, const int64_t* rowptr, const int32_t* col, const float* val,
                                 int64_t B, int64_t I, const float* feat, int64_t ldfeat, int Fdim, const float* out_bias,
                                 float* out, int64_t ldout, float* wts, ncf_stream_t stream) {
-    if (mode < 0 || mode > 2) return fail(NCF_EINVAL, "ncf_attn_forward: bad mode %d", mode);
+    if (mode < 0 || mode > 3) return fail(NCF_EINVAL, "ncf_attn_forward: bad mode %d", mode);
+    if (mode == NCF_ATT_MLP_SCALED) mode = NCF_ATT_MLP;   // w' relu(p' + q') with exact power-of-two scales IS w relu(p + q): same kernel
     if (B < 0 || I < 0 || A <= 0 || Fdim <= 0) return fail(NCF_EINVAL, "ncf_attn_forward: bad sizes");
     if (B == 0) return NCF_OK;
     if (!pc || !pr || !rowptr || !feat || !out || !wts) return fail(NCF_EINVAL, "ncf_attn_forward: null pointer");
@@ -692,8 +1101,10 @@ extern "C" int ncf_attn_forward_grouped(int mode, const float* pc, int64_t ldpc,
                                         const int64_t* wg_ptr, int64_t B, int pairs_per_wg, const float* feat, int64_t ldfeat,
                                         int Fdim, const float* out_bias, float* out, int64_t ldout, float* wts,
                                         const int64_t* wts_off, ncf_stream_t stream) {
-    if (mode != NCF_ATT_MLP && mode != NCF_ATT_COS)
+    if (mode != NCF_ATT_MLP && mode != NCF_ATT_COS && mode != NCF_ATT_MLP_SCALED)
         return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: mode %d has no LDS-tiled form (use ncf_attn_forward)", mode);
+    const bool scaled = mode == NCF_ATT_MLP_SCALED;       // only the scalar-operand form evaluates relu as a clamp; elsewhere
+    if (scaled) mode = NCF_ATT_MLP;                       // the scaled operands give the same bits through max
     if (B < 0 || R < 0 || I < 0 || A <= 0 || Fdim <= 0) return fail(NCF_EINVAL, "ncf_attn_forward_grouped: bad sizes");
     if (B == 0 || R == 0) return NCF_OK;
     if (!pc || !pr || !rowptr || !grp_ptr || !pair_ids || !wg_ptr || !feat || !out)
@@ -707,21 +1118,65 @@ extern "C" int ncf_attn_forward_grouped(int mode, const float* pc, int64_t ldpc,
         return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: needs A %% 4 == 0, A <= 256, Fdim <= 256 (A = %d, Fdim = %d)", A, Fdim);
     if (!aligned16(pc) || !aligned16(pr) || (w1 && !aligned16(w1)) || (Fdim % 4 == 0 && ldfeat % 4 == 0 && !aligned16(feat)))
         return fail(NCF_EINVAL, "ncf_attn_forward_grouped: operands must be 16-byte aligned");
-    const size_t lds = ((size_t)64 * (A + 4) + (size_t)64 * Fdim + (size_t)pairs_per_wg * A + A + 64 + 64) * 4;
-    if (lds > 160 * 1024) return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: tile needs %zu bytes of LDS", lds);
     const bool fvec = Fdim % 4 == 0 && ldfeat % 4 == 0;
-    const int pieces_per_thread = (64 * (A / 4 + (fvec ? Fdim / 4 : 0)) + 511) / 512;   // <= 16 for A, Fdim <= 256
     hipStream_t s = (hipStream_t)stream;
     // upper bound on sum_r ceil(n_r / ppw): every non-empty row adds at most one partly filled workgroup, and at most
     // min(R, B) rows are non-empty (R may be a whole user base with B pairs of a few users: device-resident evaluation)
     const unsigned blocks = (unsigned)((B + pairs_per_wg - 1) / pairs_per_wg + (R < B ? R : B));
+    // the dynamic-LDS limit of an instantiation is raised ONCE per device (to the 160 KiB a workgroup may declare)
+    auto raise_lds = [](const void* fn, std::atomic<unsigned long long>& done) -> bool {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (done.load(std::memory_order_relaxed) >> dev & 1ull) return true;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        done.fetch_or(1ull << dev, std::memory_order_relaxed);
+        return true;
+    };
+    // ---- scalar-operand form (default): tiles by LDS-DMA, aggregation on the matrix cores; 4 waves for up to 16 pairs per
+    // workgroup, 8 waves for 17..32 (half the staged bytes per pair: the choice for batches that fill the chip either way) ----
+    {
+        const int A4 = A / 4;
+        const int pp = pairs_per_wg <= 16 ? 16 : 32;
+        const int jobs = (pp / 16) * ((Fdim + 15) / 16);   // 16 x 16 output tiles of the aggregation; at most 4 per wave
+        const size_t lds2 = ((size_t)64 * (A + Fdim) + pp * 66 + pp + 2 * pp) * 4;
+        const bool sc_ok = fvec && lds2 <= 160 * 1024 && aligned16(feat) && jobs <= 4 * (pp / 4);
+        const int force = option(NCF_OPT_ATTN_GROUPED_KERNEL);
+        if (sc_ok && force != 1) {
+#define LAUNCH_SC(M, C)                                                                                                           \
+    do {                                                                                                                       \
+        static std::atomic<unsigned long long> done{0}, done2{0};                                                              \
+        if (lds2 > 64 * 1024 && !(raise_lds((const void*)attn_grouped_sc_kernel<M, C, 4>, done) &&                            \
+                                  raise_lds((const void*)attn_grouped_sc_kernel<M, C, 8>, done2)))                            \
+            return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: cannot reserve %zu bytes of LDS", lds2);                  \
+        if (pp == 16)                                                                                                          \
+            hipLaunchKernelGGL((attn_grouped_sc_kernel<M, C, 4>), dim3(blocks), dim3(256), lds2, s, pc, ldpc, pr, ldpr, A, w1, b1, rowptr, col, \
+                               val, R, I, grp_ptr, pair_ids, wg_ptr, pairs_per_wg, feat, ldfeat, Fdim, out_bias, out, ldout, wts, wts_off); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((attn_grouped_sc_kernel<M, C, 8>), dim3(blocks), dim3(512), lds2, s, pc, ldpc, pr, ldpr, A, w1, b1, rowptr, col, \
+                               val, R, I, grp_ptr, pair_ids, wg_ptr, pairs_per_wg, feat, ldfeat, Fdim, out_bias, out, ldout, wts, wts_off); \
+    } while (0)
+#define LAUNCH_SC_C(M) do { if (A4 % 32 == 0) LAUNCH_SC(M, 32); else if (A4 % 16 == 0) LAUNCH_SC(M, 16); else if (A4 % 8 == 0) LAUNCH_SC(M, 8); else LAUNCH_SC(M, 1); } while (0)
+            if (mode == NCF_ATT_MLP && scaled) LAUNCH_SC_C(3);
+            else if (mode == NCF_ATT_MLP) LAUNCH_SC_C(0);
+            else LAUNCH_SC_C(2);
+#undef LAUNCH_SC_C
+#undef LAUNCH_SC
+            return check_launch("ncf_attn_forward_grouped");
+        }
+        if (force == 2) return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: the scalar-operand form needs Fdim %% 4 == 0 and <= 160 KiB of LDS");
+    }
+    // ---- first form: tile staged through registers, operands broadcast from LDS ----
+    const size_t lds = ((size_t)64 * (A + 4) + (size_t)64 * Fdim + (size_t)pairs_per_wg * A + A + 64 + 64) * 4;
+    if (lds > 160 * 1024) return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: tile needs %zu bytes of LDS", lds);
+    const int pieces_per_thread = (64 * (A / 4 + (fvec ? Fdim / 4 : 0)) + 511) / 512;   // <= 16 for A, Fdim <= 256
 #define LAUNCH1(M, F, P)                                                                                                          \
     do {                                                                                                                       \
-        if (lds > 64 * 1024 &&                                                                                                 \
-            hipFuncSetAttribute((const void*)attn_grouped_kernel<M, F, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
-            (void)hipGetLastError();                                                                                           \
+        static std::atomic<unsigned long long> done{0};                                                                        \
+        if (lds > 64 * 1024 && !raise_lds((const void*)attn_grouped_kernel<M, F, P>, done))                                    \
             return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_grouped: cannot reserve %zu bytes of LDS", lds);                  \
-        }                                                                                                                      \
         hipLaunchKernelGGL((attn_grouped_kernel<M, F, P>), dim3(blocks), dim3(512), lds, s, pc, ldpc, pr, ldpr, A, w1, b1, rowptr, col, val, R, I, \
                            grp_ptr, pair_ids, wg_ptr, pairs_per_wg, feat, ldfeat, Fdim, out_bias, out, ldout, wts, wts_off);   \
     } while (0)

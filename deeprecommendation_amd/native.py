@@ -13,11 +13,12 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libncf_hip.so")
+LIB_PATH = os.environ.get("NCF_HIP_LIBRARY") or os.path.join(_HERE, "libncf_hip.so")   # the override is for A/B builds (tools/ab_build.sh)
 
 NCF_F32, NCF_BF16 = 0, 1
 NCF_OK, NCF_EINVAL, NCF_EUNSUPPORTED, NCF_ELAUNCH, NCF_EWORKSPACE = 0, -1, -2, -3, -4
-ATT_MLP, ATT_LINEAR, ATT_COS = 0, 1, 2
+ATT_MLP, ATT_LINEAR, ATT_COS, ATT_MLP_SCALED = 0, 1, 2, 3
+ATT_SCALE_LOG2 = 64   # include/ncf_abi.h NCF_ATT_SCALE_LOG2
 
 _c_i64 = ctypes.c_int64
 _c_p = ctypes.c_void_p
@@ -502,13 +503,14 @@ def attn_forward(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[tor
 
 def attn_grouped_supported(mode: int, A: int, Fdim: int) -> bool:
     """Shapes the LDS-tiled grouped kernel takes (mirrors ncf_attn_forward_grouped's NCF_EUNSUPPORTED conditions)."""
-    return mode in (ATT_MLP, ATT_COS) and A % 4 == 0 and A <= 256 and Fdim <= 256
+    return mode in (ATT_MLP, ATT_COS, ATT_MLP_SCALED) and A % 4 == 0 and A <= 256 and Fdim <= 256
 
 
 def default_pairs_per_wg(B: int) -> int:
-    """Pairs of one rated set per 512-thread workgroup (4 per wave at 32).  Staging a tile costs the same whatever the
-    number of pairs scored against it, so fat workgroups win as soon as there are enough of them to occupy the chip:
-    measured at config 3 (4096 pairs, 64 users) 8 / 16 / 32 -> 82 / 76 / 59 us (tools/ab_attn_grouped.py)."""
+    """Pairs of one rated set per workgroup of the grouped attention kernel (4 per wave).  32 (512 threads) stages a tile
+    for twice as many pairs as 16 (256 threads): half the gathered bytes per pair, and the tile DMAs hold a wave for about a
+    third of a tile's time.  Measured (tools/ab_attn_grouped.py, scalar-operand form, 8 / 16 / 32): config 3 (4096 pairs, 64
+    users) 59.2 / 37.9 / 34.4 us; 16 384 pairs 137.8 / 94.4 / 97.1; one user x 65 536 candidates 450.6 / 261.8 / 240.9."""
     return 32 if B >= 2048 else (16 if B >= 512 else 8)
 
 

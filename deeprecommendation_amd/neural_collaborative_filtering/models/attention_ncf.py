@@ -175,13 +175,17 @@ class AttentionNCF(_ScoringMixin, NCF):
 
     # ------------------------------------------------------------------------------------------ HIP scoring
     def _att_split(self, cache=None):
-        """Contiguous halves of AttentionNet.0 split at the cat(candidate, rated) boundary (:176)."""
+        """Contiguous halves of AttentionNet.0 split at the cat(candidate, rated) boundary (:176).  With a hidden attention
+        layer (att_dense) both halves and the bias carry the factor 2^-64 and AttentionNet's output weight 2^64
+        (native.ATT_MLP_SCALED: w1 relu(pc + pr) is unchanged bit for bit — powers of two scale exactly — and in scaled
+        units relu is the [0, 1] clamp of the kernel's packed add)."""
         cache = self._refresh() if cache is None else cache
         if "att_split" not in cache:
             l0 = self.AttentionNet[0]
             IE = self.ItemEmbeddings[0].out_features
             w = l0.weight.detach()
-            cache["att_split"] = (w[:, :IE].contiguous(), w[:, IE:].contiguous(), l0.bias.detach().contiguous())
+            f = 2.0 ** -native.ATT_SCALE_LOG2 if self.att_dense else 1.0
+            cache["att_split"] = ((w[:, :IE] * f).contiguous(), (w[:, IE:] * f).contiguous(), (l0.bias.detach() * f).contiguous())
         return cache["att_split"]
 
     def precompute_catalog(self, rated_items: torch.Tensor, cache=None):
@@ -250,9 +254,10 @@ class AttentionNCF(_ScoringMixin, NCF):
             if self.att_dense:
                 l1 = self.AttentionNet[-1]
                 if "att_out" not in cache:
-                    cache["att_out"] = (l1.weight.detach().reshape(-1).contiguous(), float(l1.bias.detach().item()))
+                    cache["att_out"] = ((l1.weight.detach().reshape(-1) * 2.0 ** native.ATT_SCALE_LOG2).contiguous(),
+                                        float(l1.bias.detach().item()))
                 w1, b1 = cache["att_out"]
-                mode = native.ATT_MLP
+                mode = native.ATT_MLP_SCALED
             else:
                 mode, w1, b1 = native.ATT_LINEAR, None, 0.0
         shared = ratings.pair_row is not None

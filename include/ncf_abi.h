@@ -235,7 +235,14 @@ int ncf_scale_rows(const float* dev_in, int64_t ldin, int64_t N, int D, float di
  *   dev_weights ((nnz,) floats aligned with the CSR entries, REQUIRED: it doubles as the score scratch) receives
  *     the attention weights w (what return_attention_weights exposes, :224).
  * ------------------------------------------------------------------------------------------------ */
-enum ncf_att_mode { NCF_ATT_MLP = 0, NCF_ATT_LINEAR = 1, NCF_ATT_COS = 2 };
+/* NCF_ATT_MLP_SCALED: NCF_ATT_MLP whose caller pre-multiplied dev_pc and dev_pr by 2^-NCF_ATT_SCALE_LOG2 and dev_w1 by
+ * 2^NCF_ATT_SCALE_LOG2 (fold the factors into the weights that produce them: exact, powers of two).  The function is
+ * unchanged bit for bit — w' relu(p' + q') == w relu(p + q) — but in scaled units every sum lies in (-1, 1), so the
+ * grouped kernel may evaluate relu as the [0, 1] CLAMP output modifier of its packed add (gfx950 has no packed fp32 max):
+ * half the vector instructions of the score loop.  Differs from relu only where |pc + pr| >= 2^64 in true units (scores
+ * that are numerically meaningless in fp32 anyway: they saturate instead of overflowing); a NaN sum gives 0 as with max. */
+enum ncf_att_mode { NCF_ATT_MLP = 0, NCF_ATT_LINEAR = 1, NCF_ATT_COS = 2, NCF_ATT_MLP_SCALED = 3 };
+#define NCF_ATT_SCALE_LOG2 64
 int ncf_attn_forward(int mode,
                      const float* dev_pc, int64_t ldpc, const float* dev_pr, int64_t ldpr, int A,
                      const float* dev_w1, float b1,
@@ -257,6 +264,8 @@ int ncf_attn_forward(int mode,
  * order.  dev_weights (optional) receives the attention weights (models/attention_ncf.py:224) in the layout of that
  * expanded CSR: pair b's weights start at dev_weights[dev_weights_off[b]] and follow its row's entries
  * (dev_weights_off (B,) = exclusive prefix sum of the row lengths of pair_row[b]).
+ * pairs_per_wg <= 16 with Fdim % 4 == 0 takes the scalar-operand form (256-thread workgroups: pc rows and w1 as scalar
+ * operands through the scalar cache, tiles by LDS-DMA, aggregation on the matrix cores); 17..32 the first form.
  * NCF_EUNSUPPORTED (fall back to ncf_attn_forward): mode NCF_ATT_LINEAR, A % 4 != 0, A > 256, Fdim > 256. */
 int ncf_attn_forward_grouped(int mode,
                              const float* dev_pc, int64_t ldpc, const float* dev_pr, int64_t ldpr, int A,
