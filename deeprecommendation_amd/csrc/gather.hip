@@ -64,6 +64,74 @@ __global__ __launch_bounds__(NCF_G_THREADS) void gather_concat_vec16(
     }
 }
 
+// Persistent form: a fixed population of waves (8 workgroups of 256 threads per CU = every wave slot of the chip) walks
+// the batch; a wave keeps THREE steps in flight — the ids of step s+2, the table rows of step s+1 and the store of step s —
+// so the dependent chain id -> row -> store of one step overlaps the next two instead of being hidden only by other
+// waves, and no wave is launched (or its registers initialised) per kilobyte moved.  Same bytes, same order per row:
+// bit-identical output.  Rows of up to 64 chunks (1 KiB).
+#ifndef NCF_G_PERSIST_U
+#define NCF_G_PERSIST_U 1     // wave steps per pipeline stage of the persistent form; interleaved A/B at cfg 2 on one box (tools/ab_gather_opt.py):
+                              // one-step-per-wave kernel 12.70-12.76 us, persistent U = 1 12.60, U = 2 12.56, U = 4 13.24 (registers); on a faster
+                              // box 12.20 -> 11.82 (U = 1), 262 144 pairs 48.1 -> 45.1
+#endif
+template <int LPP>
+__global__ __launch_bounds__(NCF_G_THREADS) void gather_concat_persistent(
+    const char* __restrict__ tabA, int64_t rowsA, int64_t ldA_bytes,
+    const char* __restrict__ tabB, int64_t rowsB, int64_t ldB_bytes,
+    const int64_t* __restrict__ idxA, const int64_t* __restrict__ idxB,
+    int64_t B, int chunksA, int chunksB, char* __restrict__ out, int64_t ldOut_bytes, int32_t* oob) {
+    constexpr int PPW = kWave / LPP;  // pairs per wave step
+    constexpr int U = NCF_G_PERSIST_U;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPP;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int cpp = chunksA + chunksB;
+    const bool isA = sub < chunksA;
+    const bool has = sub < cpp;                              // lanes beyond the row's chunks idle (cpp < LPP)
+    const int64_t coff = isA ? (int64_t)sub * 16 : (int64_t)(sub - chunksA) * 16;
+    const int64_t step = nwaves * PPW;                       // pairs between two consecutive steps of this wave
+    const int64_t stride = step * U;                         // ... and between two pipeline stages
+    auto load_id = [&](int64_t p) -> int64_t {               // the id this lane's chunk needs (its table's index array)
+        if (p >= B || !has) return -1;
+        const int64_t* ix = isA ? idxA : idxB;
+        return ix ? ix[p] : p;
+    };
+    auto load_row = [&](int64_t p, int64_t id, u32x4& v) {
+        v = u32x4{0u, 0u, 0u, 0u};
+        if (p >= B || !has) return;
+        const bool ok = (id >= 0) & (id < (isA ? rowsA : rowsB));
+        if (ok) v = *reinterpret_cast<const u32x4*>((isA ? tabA + id * ldA_bytes : tabB + id * ldB_bytes) + coff);
+        else if (oob) *oob = 1;
+    };
+    int64_t p0 = wave * PPW + lane / LPP;                    // this lane's pair of step 0
+    int64_t id0[U], id1[U];
+    u32x4 v0[U], v1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) id0[u] = load_id(p0 + u * step);
+#pragma unroll
+    for (int u = 0; u < U; ++u) id1[u] = load_id(p0 + stride + u * step);
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_row(p0 + u * step, id0[u], v0[u]);
+    for (; p0 < B; p0 += stride) {                           // (the wave leaves when its first pair is past the batch: uniform
+        int64_t id2[U];                                      //  up to the last partial wave step, whose idle lanes run along)
+#pragma unroll
+        for (int u = 0; u < U; ++u) id2[u] = load_id(p0 + 2 * stride + u * step);
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_row(p0 + stride + u * step, id1[u], v1[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t p = p0 + u * step;
+            if (has && p < B) {
+                if (NCF_G_NT_STORE) __builtin_nontemporal_store(v0[u], reinterpret_cast<u32x4*>(out + p * ldOut_bytes + (int64_t)sub * 16));
+                else *reinterpret_cast<u32x4*>(out + p * ldOut_bytes + (int64_t)sub * 16) = v0[u];
+            }
+            v0[u] = v1[u];
+            id1[u] = id2[u];
+        }
+    }
+}
+
 // Fallback for rows that are not 16-byte tileable / aligned: element-granular, ELT-byte elements.
 template <typename T>
 __global__ __launch_bounds__(256) void gather_concat_scalar(
@@ -134,6 +202,19 @@ static void launch_vec16(const char* tabA, int64_t rowsA, int64_t ldA_b, const c
                          int32_t* oob, hipStream_t s) {
     constexpr int UNROLL = NCF_G_UNROLL;
     constexpr int PPW = kWave / LPP;
+    // Persistent form once the batch gives every resident wave at least two steps; below that (and for rows beyond 64
+    // chunks) one step per wave.  ncf_set_option("gather_kernel", 1 | 2) forces one (A/B, tests).
+    const int force = option(NCF_OPT_GATHER_KERNEL);
+    const int64_t resident_waves = (int64_t)num_cus() * 8 * (NCF_G_THREADS / 64);
+    const bool persistent = cA + cB <= 64 && (force ? force == 2 : B >= 2 * resident_waves * PPW);   // >= 2 steps per resident wave
+    if (persistent) {
+        int64_t blocks = (int64_t)num_cus() * 8;
+        const int64_t need = (B + (int64_t)(NCF_G_THREADS / 64) * PPW - 1) / ((int64_t)(NCF_G_THREADS / 64) * PPW);
+        if (blocks > need) blocks = need;
+        hipLaunchKernelGGL((gather_concat_persistent<LPP>), dim3((unsigned)blocks), dim3(NCF_G_THREADS), 0, s, tabA, rowsA, ldA_b, tabB,
+                           rowsB, ldB_b, idxA, idxB, B, cA, cB, out, ldO_b, oob);
+        return;
+    }
     const int64_t pairs_per_block = (int64_t)(NCF_G_THREADS / 64) * PPW * UNROLL;
     int64_t blocks = (B + pairs_per_block - 1) / pairs_per_block;
     if (blocks > NCF_G_MAXBLOCKS) blocks = NCF_G_MAXBLOCKS;  // grid-stride beyond
