@@ -96,8 +96,11 @@ def make_model(device):
     return model
 
 
-def make_batches(device, rank):
+def make_batches(device, rank, zipf_users=False):
     g = torch.Generator().manual_seed(2024 + rank)
+    if zipf_users:
+        return [(zipf_indices(U, B, 1.05, device, 2024 + 31 * k + rank), torch.randint(0, I, (B,), generator=g).to(device))
+                for k in range(N_BATCHES)]
     return [(torch.randint(0, U, (B,), generator=g).to(device), torch.randint(0, I, (B,), generator=g).to(device))
             for _ in range(N_BATCHES)]
 
@@ -162,6 +165,23 @@ def isolated_us(fn, reps=100, settle=60):
         e1.record()
         e1.synchronize()
     return sum(e0.elapsed_time(e1) for e0, e1 in pairs) * 1e3 / reps
+
+
+def kernel_time(kernel_prefix, context, fn, reps=100, settle=60):
+    """The duration of one launch of the dominant kernel, two ways:
+      us_back_to_back  — HIP events around `reps` launches in a row (live; a launch's ramp overlaps its predecessor's tail),
+      rocprof_avg_us   — rocprofv3's serialised kernel trace of this same bench context, committed under profiles/.
+    `us` (what roofline.frac is computed from) = rocprof_avg_us when that profile is committed — the figure a reader can
+    recompute from profiles/ — else us_back_to_back."""
+    b2b = back_to_back_us(fn, reps, settle)
+    # (isolated_us() is not run here: its ~5-8 us of dispatch + event overhead per launch says nothing about the kernel, and under
+    # rocprofv3 its drained-stream launches — the chip clocks down in the gaps — would only pollute the profiler's average)
+    iso = None
+    dig = profile_digest(kernel_prefix, context) or {}
+    us = dig.get("rocprof_avg_us") or b2b
+    return {"us": us, "basis": f"rocprofv3 kernel trace, profiles/{dig['profile']}" if dig.get("rocprof_avg_us") else "HIP events, back-to-back launches (no committed profile of this context)",
+            "us_back_to_back": b2b, "us_isolated_events": iso, "rocprof_avg_us": dig.get("rocprof_avg_us"), "profile": dig.get("profile"),
+            "traffic": dig.get("traffic"), "fetch_bytes": dig.get("fetch_bytes"), "write_bytes": dig.get("write_bytes")}
 
 
 def cpu_baseline(model, seconds=12.0):
@@ -239,7 +259,8 @@ def run_cfg2(args, ctx):
     model = make_model(device)
     if args.fold:
         model.set_fold_first_layer(True)
-    batches = make_batches(device, rank)
+    batches = make_batches(device, rank, getattr(args, "zipf_users", False))
+    ctxname = "cfg2zipf" if getattr(args, "zipf_users", False) else "cfg2"
 
     def step(k):
         iu, ii = batches[k % N_BATCHES]
@@ -271,13 +292,12 @@ def run_cfg2(args, ctx):
         k = cyc[0] = (cyc[0] + 1) % N_BATCHES
         native.score_fused(tu, batches[k][0], ti, batches[k][1], packed, out=outbuf)
 
-    fused_b2b = back_to_back_us(fused)
-    fused_iso = isolated_us(fused)
-    achieved_tf = FLOP_PER_PAIR * B / (fused_iso * 1e-6) / 1e12
+    kt_f = kernel_time("ncf::score_fused_f32_kernel<128, 256, 128>", ctxname, fused)
+    achieved_tf = FLOP_PER_PAIR * B / (kt_f["us"] * 1e-6) / 1e12
     fold_info = None
     if args.fold:
         PA, PB, tail = model._folded(tu, ti, "MLP")
-        fus = isolated_us(lambda: native.score_folded(PA, batches[1][0], PB, batches[1][1], tail, out=outbuf))
+        fus = back_to_back_us(lambda: native.score_folded(PA, batches[1][0], PB, batches[1][1], tail, out=outbuf))
         ex_flop = 2 * (HIDDEN[0] * HIDDEN[1] + HIDDEN[1])
         fold_info = {"kernel": "score_folded_direct_kernel<256,128>", "bound": "mfma", "us_per_launch": fus,
                      "executed_flop_per_pair": ex_flop, "achieved": ex_flop * B / (fus * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
@@ -292,39 +312,48 @@ def run_cfg2(args, ctx):
         k = cyc[0] = (cyc[0] + 1) % N_BATCHES
         native.gather_concat(tu, batches[k][0], ti, batches[k][1], out=gbuf)
 
-    gather_b2b = back_to_back_us(gather)
-    gather_iso = isolated_us(gather)
-    gather_gbs = GATHER_BYTES_PER_PAIR * B / (gather_iso * 1e-6) / 1e9
+    kt_g = kernel_time("ncf::gather_concat", ctxname, gather)
+    gather_gbs = GATHER_BYTES_PER_PAIR * B / (kt_g["us"] * 1e-6) / 1e9
 
-    # ---- SURVEY §8d cfg 2 variants: Zipf(1.05) user ids, and the [256]-only MLP (train_model.py:40-42 default) ----
-    zu = zipf_indices(U, B, 1.05, device, 2024)
-    zi = batches[0][1]
-    zipf_fused_us = isolated_us(lambda: native.score_fused(tu, zu, ti, zi, packed, out=outbuf))
-    lin = [m for m in model.MLP if isinstance(m, torch.nn.Linear)]
-    g2 = torch.Generator(device=device).manual_seed(7)
-    w_last = (torch.rand((1, HIDDEN[0]), device=device, generator=g2) * 2 - 1) / HIDDEN[0] ** 0.5
-    packed256 = native.PackedMLP([lin[0].weight, w_last], [lin[0].bias, lin[2].bias])
-    h256_us = isolated_us(lambda: native.score_fused(tu, batches[1][0], ti, batches[1][1], packed256, out=outbuf))
-    zipf_gather_us = isolated_us(lambda: native.gather_concat(tu, zu, ti, zi, out=gbuf))
-    # opt-in variant (BasicNCF.set_fold_first_layer): layer 1 folded into 256-wide tables; reported beside the default
-    # line, never as `value` (its results agree with the oracle to 1e-5 but are not bit-identical to the default kernel's)
-    fold_variant = None
-    if fold_info is None and native.folded_supported(HIDDEN[0], HIDDEN[1]):
-        try:
-            PAv, PBv, tailv = model._folded(tu, ti, "MLP")
-            fv_us = isolated_us(lambda: native.score_folded(PAv, batches[1][0], PBv, batches[1][1], tailv, out=outbuf))
-            fold_variant = {"fused_us_per_launch": fv_us, "fused_pairs_per_s": B / (fv_us * 1e-6),
-                            "executed_flop_per_pair": 2 * (HIDDEN[0] * HIDDEN[1] + HIDDEN[1]),
-                            "bytes_per_pair": 2 * HIDDEN[0] * 4 + 2 * 8 + 4,
-                            "table_bytes": int(PAv.numel() + PBv.numel()) * 4}
-            del PAv, PBv
-        except Exception as exc:  # the variant must never take the default line down
-            fold_variant = {"error": str(exc)}
+    variants = None
+    if not getattr(args, "no_variants", False):
+        # ---- SURVEY §8d cfg 2 variants: Zipf(1.05) user ids, and the [256]-only MLP (train_model.py:40-42 default) ----
+        zu = zipf_indices(U, B, 1.05, device, 2024)
+        zi = batches[0][1]
+        zipf_fused_us = back_to_back_us(lambda: native.score_fused(tu, zu, ti, zi, packed, out=outbuf))
+        lin = [m for m in model.MLP if isinstance(m, torch.nn.Linear)]
+        g2 = torch.Generator(device=device).manual_seed(7)
+        w_last = (torch.rand((1, HIDDEN[0]), device=device, generator=g2) * 2 - 1) / HIDDEN[0] ** 0.5
+        packed256 = native.PackedMLP([lin[0].weight, w_last], [lin[0].bias, lin[2].bias])
+        h256_us = back_to_back_us(lambda: native.score_fused(tu, batches[1][0], ti, batches[1][1], packed256, out=outbuf))
+        zipf_gather_us = back_to_back_us(lambda: native.gather_concat(tu, zu, ti, zi, out=gbuf))
+        dig_z = profile_digest("ncf::gather_concat", "cfg2zipf") or {}
+        flop256 = 2 * (2 * E * HIDDEN[0] + HIDDEN[0])
+        variants = {
+            "zipf_1.05_users": {"fused_us_per_launch": zipf_fused_us, "fused_pairs_per_s": B / (zipf_fused_us * 1e-6),
+                                "gather_us_per_launch": zipf_gather_us, "gather_rocprof_avg_us": dig_z.get("rocprof_avg_us"),
+                                "gather_profile": dig_z.get("profile"),
+                                "gather_GBps_algorithmic": GATHER_BYTES_PER_PAIR * B / (zipf_gather_us * 1e-6) / 1e9,
+                                "note": "back-to-back HIP-event timings; hot rows are cache hits, so the algorithmic rate is not an HBM figure"},
+            "mlp_256_only": {"fused_us_per_launch": h256_us, "fused_pairs_per_s": B / (h256_us * 1e-6),
+                             "flop_per_pair": flop256, "frac_of_fp32_mfma_peak": flop256 * B / (h256_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+        }
+        # opt-in variant (BasicNCF.set_fold_first_layer): layer 1 folded into 256-wide tables; reported beside the default
+        # line, never as `value` (its results agree with the oracle to 1e-5 but are not bit-identical to the default kernel's)
+        if fold_info is None and native.folded_supported(HIDDEN[0], HIDDEN[1]):
+            try:
+                PAv, PBv, tailv = model._folded(tu, ti, "MLP")
+                fv_us = back_to_back_us(lambda: native.score_folded(PAv, batches[1][0], PBv, batches[1][1], tailv, out=outbuf))
+                variants["folded_first_layer_opt_in"] = {"fused_us_per_launch": fv_us, "fused_pairs_per_s": B / (fv_us * 1e-6),
+                                                         "executed_flop_per_pair": 2 * (HIDDEN[0] * HIDDEN[1] + HIDDEN[1]),
+                                                         "bytes_per_pair": 2 * HIDDEN[0] * 4 + 2 * 8 + 4,
+                                                         "table_bytes": int(PAv.numel() + PBv.numel()) * 4}
+                del PAv, PBv
+            except Exception as exc:  # the variant must never take the default line down
+                variants["folded_first_layer_opt_in"] = {"error": str(exc)}
 
     if rank != 0:
         return None
-    dig_f = profile_digest("ncf::score_fused_f32_kernel<128, 256, 128>", "cfg2") or {}
-    dig_g = profile_digest("ncf::gather_concat", "cfg2") or {}
     total_pairs = world * B * args.steps
     line = {
         "metric": "scored user-item pairs/sec",
@@ -341,34 +370,29 @@ def run_cfg2(args, ctx):
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "cfg2: BasicNCF 1M users x 100k items, emb_dim=64, batch=65536/GPU, fp32, MLP 128-256-128-1"
+                               + (" [Zipf(1.05) user ids]" if ctxname == "cfg2zipf" else "")
                                + (" [first MLP layer FOLDED into 256-wide tables: 65 792 executed FLOP and 2068 B per pair]" if args.fold else ""),
                    "parallelism": f"replicas x{world} (tables+MLP replicated, batch split, no collective)"},
         "roofline": {"kernel": "score_fused_f32_kernel<128,256,128>", "bound": "mfma", "achieved": achieved_tf,
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                     "traffic": dig_f.get("traffic"), "us_per_launch": fused_iso, "us_back_to_back": fused_b2b,
+                     "traffic": kt_f["traffic"], "us_per_launch": kt_f["us"], "us_per_launch_basis": kt_f["basis"],
+                     "us_back_to_back": kt_f["us_back_to_back"], "us_isolated_events": kt_f["us_isolated_events"],
+                     "rocprof_avg_us": kt_f["rocprof_avg_us"], "profile": kt_f["profile"],
+                     "frac_from_timed_region": FLOP_PER_PAIR * B / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                      "algorithmic_flop_per_pair": FLOP_PER_PAIR, "algorithmic_bytes_per_pair": FUSED_BYTES_PER_PAIR,
                      "algorithmic_bytes_per_launch": FUSED_BYTES_PER_PAIR * B,
-                     "rocprof_avg_us": dig_f.get("rocprof_avg_us"), "profile": dig_f.get("profile"),
-                     "note": "us_per_launch (and frac) = isolated launches, HIP events around each, stream drained between them; "
-                             "us_back_to_back = 100 launches in a row (a launch's ramp overlaps the previous launch's tail)"},
-        "gather_roofline": {"kernel": "gather_concat (standalone K1)", "bound": "hbm", "achieved": gather_gbs,
+                     "note": "frac = algorithmic FLOP per launch / us_per_launch; frac_from_timed_region divides by the driver-visible "
+                             "step time instead (one launch per step plus the host's enqueue gaps: a lower bound)"},
+        "gather_roofline": {"kernel": "gather_concat_persistent<32> (standalone K1)", "bound": "hbm", "achieved": gather_gbs,
                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gather_gbs / PEAK_HBM_GBS,
-                            "traffic": dig_g.get("traffic"), "us_per_launch": gather_iso, "us_back_to_back": gather_b2b,
-                            "ids": "uniform", "algorithmic_bytes_per_pair": GATHER_BYTES_PER_PAIR,
-                            "algorithmic_bytes_per_launch": GATHER_BYTES_PER_PAIR * B,
-                            "rocprof_avg_us": dig_g.get("rocprof_avg_us"), "profile": dig_g.get("profile")},
+                            "traffic": kt_g["traffic"], "us_per_launch": kt_g["us"], "us_per_launch_basis": kt_g["basis"],
+                            "us_back_to_back": kt_g["us_back_to_back"], "us_isolated_events": kt_g["us_isolated_events"],
+                            "rocprof_avg_us": kt_g["rocprof_avg_us"], "profile": kt_g["profile"],
+                            "ids": "Zipf(1.05) users" if ctxname == "cfg2zipf" else "uniform",
+                            "algorithmic_bytes_per_pair": GATHER_BYTES_PER_PAIR, "algorithmic_bytes_per_launch": GATHER_BYTES_PER_PAIR * B},
     }
-    flop256 = 2 * (2 * E * HIDDEN[0] + HIDDEN[0])
-    line["variants"] = {
-        "zipf_1.05_users": {"fused_us_per_launch": zipf_fused_us, "fused_pairs_per_s": B / (zipf_fused_us * 1e-6),
-                            "gather_us_per_launch": zipf_gather_us,
-                            "gather_GBps_algorithmic": GATHER_BYTES_PER_PAIR * B / (zipf_gather_us * 1e-6) / 1e9,
-                            "note": "hot rows are cache hits: the algorithmic rate may exceed the HBM peak; not the roofline figure"},
-        "mlp_256_only": {"fused_us_per_launch": h256_us, "fused_pairs_per_s": B / (h256_us * 1e-6),
-                         "flop_per_pair": flop256, "frac_of_fp32_mfma_peak": flop256 * B / (h256_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS},
-    }
-    if fold_variant is not None:
-        line["variants"]["folded_first_layer_opt_in"] = fold_variant
+    if variants is not None:
+        line["variants"] = variants
     if fold_info is not None:
         line["folded_roofline"] = fold_info
     if world == 1 and not args.no_cpu_baseline:
@@ -450,6 +474,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fold", action="store_true",
                     help="opt-in: fold the first MLP layer into the tables (BasicNCF.set_fold_first_layer); NOT the default line")
+    ap.add_argument("--no-variants", action="store_true", help="cfg2: skip the variants block (profiling runs: one id distribution per run)")
+    ap.add_argument("--zipf-users", action="store_true", help="cfg2: Zipf(1.05) user ids instead of uniform ones (its own profile context)")
     ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5", "train2"],
                     help="one config alone (cfg2 = the headline line without other_configs); default: headline + other_configs")
     args = ap.parse_args()

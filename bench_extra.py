@@ -132,29 +132,36 @@ def run_cfg4(args, ctx):
     x = model._node_table0(graph)
     z = conv.hoisted(x, prep)
     y = torch.empty((N, D), device=device)
-    us = bench.isolated_us(lambda: prep.csr.spmm(z, y=y), reps=20, settle=5)
-    us_b2b = bench.back_to_back_us(lambda: prep.csr.spmm(z, y=y), reps=20, settle=5)
-    gemm_us = bench.isolated_us(lambda: conv.hoisted(x, prep), reps=20, settle=5)
+    kt = bench.kernel_time("ncf::spmm_seg_kernel", "cfg4", lambda: prep.csr.spmm(z, y=y), reps=20, settle=5)
+    # one SpMM layer = the edge pass + the (small) ordered partial-sum tree of the hub rows: live timings cover the whole layer,
+    # rocprof's average is per spmm_seg_kernel LAUNCH (edge pass and tree levels mixed), so the layer's time stays live here
+    us = kt["us_back_to_back"]
+    gemm_us = bench.back_to_back_us(lambda: conv.hoisted(x, prep), reps=20, settle=5)
     bytes_per_edge = D * 4 + 4 + 4
     alg = E * bytes_per_edge + N * D * 4  # + the output rows written once
     gbs = alg / (us * 1e-6) / 1e9
-    dig = bench.profile_digest("ncf::spmm_seg_kernel", "cfg4") or {}
+    dig = bench.profile_digest("ncf::spmm_layer", "cfg4") or {}   # tools/summarize_profile.py: the layer's launches summed
     traffic = dig.get("traffic")
+    hbm_gbs = None if traffic is None else traffic / (us * 1e-6) / 1e9
     line = {"metric": "LightGCN propagated directed edges/sec", "value": L * E * args.steps / wall, "unit": "edges/s", "n_gpus": 1,
             "steps": args.steps, "warmup": warm, "warmup_requested": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg4: GraphNCF {L}-layer LightGCN, {U} users x {I} items, {E} directed edges (Zipf items), D={D}, hetero, mean",
                        "graph_prep_s": prep_s, "segments": int(prep.segptr.numel() - 1)},
             "roofline": {"kernel": f"spmm_seg_kernel<32> x{len(prep.csr.levels)} levels (edge pass + ordered partial tree), one layer",
-                         "bound": "hbm", "achieved": gbs, "peak": bench.PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / bench.PEAK_HBM_GBS,
-                         "traffic": traffic, "us_per_launch": us, "us_back_to_back": us_b2b,
+                         "bound": "hbm",
+                         # frac is the COUNTER figure when the PMC profile of this context is committed: bytes that actually crossed
+                         # the L2's memory side (FETCH x2 + WRITE) per layer over the layer's time; the algorithmic rate beside it
+                         "achieved": hbm_gbs if hbm_gbs is not None else gbs, "peak": bench.PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": (hbm_gbs if hbm_gbs is not None else gbs) / bench.PEAK_HBM_GBS,
+                         "frac_basis": "PMC bytes per layer / layer time" if hbm_gbs is not None else "ALGORITHMIC bytes / layer time (no committed PMC profile)",
+                         "traffic": traffic, "us_per_launch": us, "us_isolated_events": kt["us_isolated_events"],
+                         "rocprof_layer_us": dig.get("rocprof_avg_us"), "profile": dig.get("profile"),
                          "algorithmic_bytes_per_edge": bytes_per_edge, "algorithmic_bytes_per_launch": alg,
-                         "hbm_GBps_from_counters": None if traffic is None else traffic / (us * 1e-6) / 1e9,
-                         "hbm_frac_from_counters": None if traffic is None else traffic / (us * 1e-6) / 1e9 / bench.PEAK_HBM_GBS,
-                         "rocprof_avg_us": dig.get("rocprof_avg_us"), "profile": dig.get("profile"), "hoisted_gemm_us": gemm_us,
-                         "note": "achieved / frac are ALGORITHMIC bytes (520 B per edge) over the layer's time; the 51 MB of item rows "
-                                 "(half of all source reads) are served by the Infinity Cache, so the bytes that reach HBM are fewer: "
-                                 "hbm_GBps_from_counters is the PMC figure (FETCH x2 + WRITE of the edge-pass kernel) over the same time"}}
+                         "algorithmic_GBps": gbs, "algorithmic_frac_of_hbm_peak": gbs / bench.PEAK_HBM_GBS,
+                         "hoisted_gemm_us": gemm_us,
+                         "note": "the algorithmic rate (520 B per edge) can exceed the HBM peak: the 51 MB of item rows — half of all source "
+                                 "reads — are served by the Infinity Cache and never reach HBM; what did is the counter figure"}}
     if not getattr(args, "no_cpu_baseline", False):
         line["cpu_baseline"] = _cfg4_cpu_baseline(model, D)
     return line
@@ -267,7 +274,7 @@ def run_cfg3(args, ctx):
         bias_u = model.UserEmbeddings[0].bias.detach()
         rs = batches[0][1] if not per_pair else None
         rx = r.expanded()
-        us_pp = bench.isolated_us(lambda: native.attn_forward(native.ATT_MLP_SCALED, pc, pr, w1, b1, rx.rowptr, rx.col, rx.val, proj, out_bias=bias_u), reps=50, settle=10)
+        us_pp = bench.back_to_back_us(lambda: native.attn_forward(native.ATT_MLP_SCALED, pc, pr, w1, b1, rx.rowptr, rx.col, rx.val, proj, out_bias=bias_u), reps=50, settle=10)
         ppw = native.default_pairs_per_wg(B)
         us_g = us_g_b2b = us_group_prep = None
         if not per_pair:
@@ -277,11 +284,13 @@ def run_cfg3(args, ctx):
                 return native.attn_forward_grouped(native.ATT_MLP_SCALED, pc, pr, w1, b1, rs.rowptr, rs.col, rs.val, rs.pair_row, proj, out_bias=bias_u,
                                                    grouping=grouping)
 
-            us_g = bench.isolated_us(grouped, reps=50, settle=20)
-            us_g_b2b = bench.back_to_back_us(grouped, reps=50, settle=20)
-            us_group_prep = bench.isolated_us(lambda: native.group_pairs(rs.pair_row, rs.rowptr.numel() - 1, ppw), reps=50, settle=5)
-        lin_us = bench.isolated_us(lambda: native.linear(cand, li.weight.detach(), li.bias.detach()), reps=50, settle=5)
-    us = us_pp if per_pair else us_g
+            kt = bench.kernel_time("ncf::attn_grouped_sc_kernel", "cfg3", grouped, reps=50, settle=20)
+            us_g, us_g_b2b = kt["us"], kt["us_back_to_back"]
+            us_group_prep = bench.back_to_back_us(lambda: native.group_pairs(rs.pair_row, rs.rowptr.numel() - 1, ppw), reps=50, settle=5)
+        else:
+            kt = bench.kernel_time("ncf::attn_kernel", "cfg3", lambda: native.attn_forward(native.ATT_MLP_SCALED, pc, pr, w1, b1, rx.rowptr, rx.col, rx.val, proj, out_bias=bias_u), reps=50, settle=10)
+        lin_us = bench.back_to_back_us(lambda: native.linear(cand, li.weight.detach(), li.bias.detach()), reps=50, settle=5)
+    us = kt["us"]
     # What the kernel executes per (pair, rated entry): A x (add, max, fma) for the score (4 flop per a) + UE x fma for the
     # aggregation (2 flop per feature) + the softmax arithmetic — the reformulated attention (AttentionNet.0 split at the cat
     # boundary, UserEmbeddings linearity), NOT the reference's per-pair (2 IE -> A) GEMM.  Its operands come from LDS / cache
@@ -291,7 +300,6 @@ def run_cfg3(args, ctx):
     bytes_per_pair_pp = nnz * (A * 4 + UE * 4 + 4 + 4 + 3 * 4)   # pr row + projected row + col + val + weights r/w
     bytes_per_pair_g = nnz * (A * 4 + UE * 4 + 4 + 4) / ppw + A * 4 + UE * 4 + 8
     bpp = bytes_per_pair_pp if per_pair else bytes_per_pair_g
-    dig = bench.profile_digest("ncf::attn_kernel" if per_pair else "ncf::attn_grouped", "cfg3") or {}
     line = {"metric": "AttentionNCF scored pairs/sec", "value": B * args.steps / wall, "unit": "pairs/s", "n_gpus": 1,
             "steps": args.steps, "warmup": warm, "warmup_requested": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -305,14 +313,15 @@ def run_cfg3(args, ctx):
                        "eager_ms_per_step": wall_eager / args.steps * 1e3, "eager_pairs_per_s": B * args.steps / wall_eager,
                        "graph_replay_ms_per_step": None if wall_graph is None else wall_graph / args.steps * 1e3,
                        "graph_error": graph_err},
-            "roofline": {"kernel": "attn_kernel<0>" if per_pair else "attn_grouped_kernel<0>", "bound": "valu", "achieved": tf,
+            "roofline": {"kernel": "attn_kernel<0>" if per_pair else "attn_grouped_sc_kernel<3,32,8>", "bound": "valu", "achieved": tf,
                          "peak": bench.PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / bench.PEAK_F32_MFMA_TFLOPS,
-                         "traffic": dig.get("traffic"), "us_per_launch": us, "us_back_to_back": us_g_b2b,
+                         "traffic": kt["traffic"], "us_per_launch": us, "us_per_launch_basis": kt["basis"], "us_back_to_back": kt["us_back_to_back"],
+                         "us_isolated_events": kt["us_isolated_events"],
                          "algorithmic_flop_per_pair": flop_per_pair, "algorithmic_bytes_per_pair": bpp,
                          "algorithmic_bytes_per_launch": bpp * B, "hbm_GBps_at_this_rate": bpp * B / (us * 1e-6) / 1e9,
                          "per_pair_kernel_us": us_pp, "grouped_kernel_us": us_g, "grouping_prep_us": us_group_prep,
                          "pairs_per_workgroup": ppw, "candidate_linear_us": lin_us,
-                         "rocprof_avg_us": dig.get("rocprof_avg_us"), "profile": dig.get("profile"),
+                         "rocprof_avg_us": kt["rocprof_avg_us"], "profile": kt["profile"],
                          "note": "bound = fp32 vector (VALU) issue: the contract's hbm/mfma pair does not describe this kernel — its tiles come "
                                  "from L2 / the Infinity Cache once per workgroup (hbm_GBps_at_this_rate is what it NEEDS, a few % of HBM), "
                                  "and relu sits between the add and the dot, so the matrix cores cannot take the (pair, entry, a) loop; "
@@ -380,6 +389,10 @@ def run_cfg5(args, ctx):
     strong = os.environ.get("NCF_CFG5_STRONG") == "1"   # fixed global batch of 65 536 pairs (SURVEY 8d cfg 5, second form)
     if strong:
         B = B // world
+    if os.environ.get("NCF_CFG5_LOCAL_BATCH"):           # its own profile context (profiles/<tag>_cfg5_b<B>_*): the 1 M-pair point
+        B = int(os.environ["NCF_CFG5_LOCAL_BATCH"])
+    ctxname = "cfg5" if B == 65_536 else f"cfg5_b{B}"
+    big = not getattr(args, "no_variants", False) and B == 65_536
     replicate = os.environ.get("NCF_REPLICATE_ITEMS", "1") == "1"
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     ulo, uhi = RowShardedTable.shard_bounds(U, world, rank)
@@ -454,20 +467,28 @@ def run_cfg5(args, ctx):
     lu = torch.randint(0, tu.shape[0], (B,), device=device, generator=gl)
     li = torch.randint(0, ti.shape[0], (B,), device=device, generator=gl)
     out = torch.empty((B, 1), device=device)
-    us = bench.isolated_us(lambda: native.score_fused(tu, lu, ti, li, model.packed, out=out), reps=100, settle=60)
-    us_b2b = bench.back_to_back_us(lambda: native.score_fused(tu, lu, ti, li, model.packed, out=out), reps=100, settle=60)
+    kt = bench.kernel_time("ncf::score_ws_bf16_kernel", ctxname, lambda: native.score_fused(tu, lu, ti, li, model.packed, out=out), reps=100, settle=60)
+    us, us_b2b = kt["us"], kt["us_back_to_back"]
     flop = 2 * (256 * 256 + 256 * 128 + 128)
     tf = flop * B / (us * 1e-6) / 1e12
-    # the same kernel on a 16x larger local batch (north_star: ">= 50 % MFMA utilisation on the MLP at emb_dim = 128")
+    # the same kernel on a 16x larger local batch (north_star: ">= 50 % MFMA utilisation on the MLP at emb_dim = 128"); skipped
+    # under the profiler (--no-variants): the same kernel name at another size would pollute rocprof's per-kernel average —
+    # that point has its own context (NCF_CFG5_LOCAL_BATCH=1048576 -> profiles/<tag>_cfg5_b1048576_*)
     BL = 16 * B
-    lu2 = torch.randint(0, tu.shape[0], (BL,), device=device, generator=gl)
-    li2 = torch.randint(0, ti.shape[0], (BL,), device=device, generator=gl)
-    outl = torch.empty((BL, 1), device=device)
-    usl = bench.isolated_us(lambda: native.score_fused(tu, lu2, ti, li2, model.packed, out=outl), reps=30, settle=10)
-    tfl = flop * BL / (usl * 1e-6) / 1e12
+    big_variant = None
+    if big:
+        lu2 = torch.randint(0, tu.shape[0], (BL,), device=device, generator=gl)
+        li2 = torch.randint(0, ti.shape[0], (BL,), device=device, generator=gl)
+        outl = torch.empty((BL, 1), device=device)
+        ktl = bench.kernel_time("ncf::score_ws_bf16_kernel", f"cfg5_b{BL}", lambda: native.score_fused(tu, lu2, ti, li2, model.packed, out=outl), reps=30, settle=10)
+        tfl = flop * BL / (ktl["us"] * 1e-6) / 1e12
+        big_variant = {"kernel": "score_ws_bf16_kernel<256,256,128>", "us_per_launch": ktl["us"], "us_per_launch_basis": ktl["basis"],
+                       "us_back_to_back": ktl["us_back_to_back"], "rocprof_avg_us": ktl["rocprof_avg_us"], "profile": ktl["profile"],
+                       "pairs_per_s": BL / (ktl["us"] * 1e-6), "achieved_TFLOPs": tfl, "frac_of_bf16_mfma_peak": tfl / bench.PEAK_BF16_MFMA_TFLOPS,
+                       "hbm_GBps_at_this_rate": 532 * BL / (ktl["us"] * 1e-6) / 1e9}
+        del lu2, li2, outl
     if rank != 0:
         return None
-    dig = bench.profile_digest("ncf::score_ws_bf16_kernel", "cfg5") or {}
     line = {"metric": "scored user-item pairs/sec", "value": world * B * args.steps / main_wall, "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": main_warm, "warmup_requested": args.warmup, "ms_per_step": main_wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -478,14 +499,12 @@ def run_cfg5(args, ctx):
                                    "on a second stream under step t's MLP; value = the fastest form below"},
             "exchange_forms": forms,
             "roofline": {"kernel": "score_ws_bf16_kernel<256,256,128>", "bound": "mfma", "achieved": tf, "peak": bench.PEAK_BF16_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tf / bench.PEAK_BF16_MFMA_TFLOPS, "traffic": dig.get("traffic"), "us_per_launch": us,
-                         "us_back_to_back": us_b2b, "algorithmic_flop_per_pair": flop, "algorithmic_bytes_per_pair": 532,
+                         "unit": "TFLOP/s", "frac": tf / bench.PEAK_BF16_MFMA_TFLOPS, "traffic": kt["traffic"], "us_per_launch": us,
+                         "us_per_launch_basis": kt["basis"], "us_back_to_back": us_b2b, "us_isolated_events": kt["us_isolated_events"],
+                         "algorithmic_flop_per_pair": flop, "algorithmic_bytes_per_pair": 532,
                          "algorithmic_bytes_per_launch": 532 * B, "hbm_GBps_at_this_rate": 532 * B / (us * 1e-6) / 1e9,
-                         "rocprof_avg_us": dig.get("rocprof_avg_us"), "profile": dig.get("profile")},
-            "variants": {"local_batch_1048576": {
-                "kernel": "score_ws_bf16_kernel<256,256,128>", "us_per_launch": usl, "pairs_per_s": BL / (usl * 1e-6),
-                "achieved_TFLOPs": tfl, "frac_of_bf16_mfma_peak": tfl / bench.PEAK_BF16_MFMA_TFLOPS,
-                "hbm_GBps_at_this_rate": 532 * BL / (usl * 1e-6) / 1e9}}}
+                         "rocprof_avg_us": kt["rocprof_avg_us"], "profile": kt["profile"]},
+            "variants": {f"local_batch_{BL}": big_variant}}
     if world == 1 and not getattr(args, "no_cpu_baseline", False):
         line["cpu_baseline"] = _cfg5_cpu_baseline(ws, bs, E, B)
     return line

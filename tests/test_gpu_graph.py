@@ -87,7 +87,9 @@ def test_graph_long_rows_are_split_and_deterministic(gpu, monkeypatch):
             return mm(graph, users.to(gpu), items.to(gpu), gpu)
 
     o1, o2 = run(), run()
-    assert_close(o1, ref)
+    # the hub row sums ~3000 signed terms (and the fp32 CPU oracle adds them in another order): the summation-order difference
+    # scales with sum|terms|, far above the cancelled results, so the absolute part of the bar is 1e-5 of the largest output here
+    assert_close(o1, ref, floor=1.0)
     assert torch.equal(o1, o2)
 
 

@@ -76,9 +76,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "pmc":
     grouping = (native.group_pairs(who, users, ppw), ppw)
     f = 2.0 ** -native.ATT_SCALE_LOG2
     pcs, prs, w1s = pc * f, pr * f, w1 / f
-    native.set_option("attn_grouped_kernel", "scalar")
-    for _ in range(10):
-        native.attn_forward_grouped(native.ATT_MLP_SCALED, pcs, prs, w1s, 0.1, rowptr, col, val, who, feat, grouping=grouping)
+    for kern, ppw in (("lds", 32), ("scalar", 32)):        # round 1's kernel and this round's, each at its own best group size
+        grouping = (native.group_pairs(who, users, ppw), ppw)
+        native.set_option("attn_grouped_kernel", kern)
+        for _ in range(20):
+            native.attn_forward_grouped(native.ATT_MLP_SCALED, pcs, prs, w1s, 0.1, rowptr, col, val, who, feat, grouping=grouping)
     torch.cuda.synchronize()
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "threshold":

@@ -1,4 +1,5 @@
-"""Condense gpurun_out/prof_<tag>/ (tools/profile.sh output) into profiles/<tag>_*.csv + profiles/<tag>_summary.md.
+"""Condense gpurun_out/prof_<tag>_<ctx>/ (tools/profile_round.sh output) into profiles/<tag>_<ctx>_{kernel_stats.csv, pmc.csv,
+summary.md, digest.json, bench.json}.     python tools/summarize_profile.py <tag> <ctx>
 
 Only this repo's kernels (ncf::*) are kept — torch's initialisation kernels have kilobyte-long names.
 PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
@@ -19,14 +20,21 @@ def short(name):
     return m.group(1) if m else name[:60]
 
 
-def main(tag):
+def main(tag, ctx=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+    src = os.path.join(root, "gpurun_out", f"prof_{tag}" + (f"_{ctx}" if ctx else ""))
     dst = os.path.join(root, "profiles")
     os.makedirs(dst, exist_ok=True)
+    if ctx:
+        tag = f"{tag}_{ctx}"
+    cmd = "bench.py"
+    try:
+        cmd = open(os.path.join(src, "command.txt")).read().strip()
+    except OSError:
+        pass
     lines = [f"# rocprofv3 summary — {tag}", "",
-             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline`",
-             "(plus one `--pmc` pass per counter group; see tools/profile.sh).  Only `ncf::` kernels listed.", ""]
+             f"Command: `rocprofv3 --kernel-trace --stats -- python3 {cmd}`",
+             "(plus one `--pmc` pass per counter group, each its own run; see tools/profile_round.sh).  Only `ncf::` kernels listed.", ""]
     stats = os.path.join(src, "trace", "trace_kernel_stats.csv")
     rows = []
     if os.path.exists(stats):
@@ -88,6 +96,31 @@ def main(tag):
             d["mfma_busy_cycles"] = sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(cs["SQ_VALU_MFMA_BUSY_CYCLES"])
         if "GRBM_GUI_ACTIVE" in cs:
             d["gui_active_cycles_sum8xcd"] = sum(cs["GRBM_GUI_ACTIVE"]) / len(cs["GRBM_GUI_ACTIVE"])
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "SQ_WAVES"):
+            if c in cs:
+                d[c.lower()] = sum(cs[c]) / len(cs[c])
+    # the bench line printed by the profiled trace run (its live timings were taken UNDER the profiler)
+    bj = os.path.join(src, "bench.json")
+    bench_line = None
+    if os.path.exists(bj) and os.path.getsize(bj) > 0:
+        try:
+            bench_line = json.loads(open(bj).read().strip().splitlines()[-1])
+            with open(os.path.join(dst, f"{tag}_bench_under_profiler.json"), "w") as f:
+                json.dump(bench_line, f, indent=1)
+        except ValueError:
+            bench_line = None
+    # cfg 4: one LightGCN layer = one spmm_seg_kernel launch per level of the segment tree (edge pass + ordered partial sums);
+    # every layer has exactly one launch per level, so layer totals = per-launch means x levels
+    if bench_line is not None:
+        m = re.search(r"x(\d+) levels", str((bench_line.get("roofline") or {}).get("kernel", "")))
+        seg = [k for k in digest["kernels"] if k.startswith("ncf::spmm_seg_kernel")]
+        if m and seg:
+            lv = int(m.group(1))
+            d = digest["kernels"][seg[0]]
+            digest["kernels"]["ncf::spmm_layer"] = {k: v * lv for k, v in d.items() if isinstance(v, (int, float))}
+            digest["kernels"]["ncf::spmm_layer"]["levels"] = lv
+            lines += [f"One LightGCN layer = {lv} `{seg[0]}` launches (edge pass + ordered partial-sum tree): per-layer figures = per-launch means x {lv}:",
+                      "", "```", json.dumps(digest["kernels"]["ncf::spmm_layer"], indent=1), "```", ""]
     if digest["kernels"]:
         with open(os.path.join(dst, f"{tag}_digest.json"), "w") as f:
             json.dump(digest, f, indent=1)
@@ -97,4 +130,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02", sys.argv[2] if len(sys.argv) > 2 else None)
