@@ -6,6 +6,10 @@ layers; loss, dropout masks and the optimizer stay torch ops (the reference's tr
   LinearFn       : forward ncf_linear_forward (ReLU fused in the epilogue);
                    backward dX = dY . W (row-streaming GEMM with W^T), dW = dY^T . X (ncf_gemm_tn, ordered split over
                    the batch), db = ncf_colsum, ReLU mask = ncf_relu_backward_out
+  SpmmFn         : LightGCN propagation y = A z (ncf_spmm_csr on the CSR by destination); backward dz = A^T dy = the SAME
+                   kernel on the CSR by source (gnn_ncf.py:74-94 through autograd in the reference); optional per-edge
+                   message dropout regenerated from a hash in both directions (ncf_spmm_csr_dropout)
+  AttnFn         : grouped item-item attention (ncf_attn_forward_grouped) with its backward (ncf_attn_backward_grouped)
 """
 import torch
 
@@ -112,6 +116,29 @@ class GatherColumnsConcatFn(torch.autograd.Function):
             d_ba = db[:ea] if ctx.has_bias[0] and ctx.needs_input_grad[1] else None
             d_bb = db[ea:] if ctx.has_bias[1] and ctx.needs_input_grad[4] else None
         return d_wa, d_ba, None, d_wb, d_bb, None
+
+
+class SpmmFn(torch.autograd.Function):
+    """y (N, D) = sum over the edges into each destination of coef_e * [dropout mask / (1 - p)] * z[src_e]  —  one LightGCN
+    aggregation (gnn_ncf.py:52-70, 74-94).  ``prep`` is the PreparedGraph (CSR by destination + its transpose, built once per
+    graph); ``coef`` the per-edge coefficients in CSR order (a training step recomputes them when it masks the batch's target
+    edges); ``dropout`` = (p, seed) or None.  The coefficients are data, not parameters: no gradient flows to them."""
+
+    @staticmethod
+    def forward(ctx, z, prep, coef, dropout):
+        ctx.prep, ctx.dropout = prep, dropout
+        ctx.save_for_backward(coef)
+        drop = None if dropout is None or dropout[0] <= 0 else (dropout[0], dropout[1], None)
+        return prep.csr.spmm(z.contiguous(), coef=coef, dropout=drop)
+
+    @staticmethod
+    def backward(ctx, dY):
+        (coef,) = ctx.saved_tensors
+        prep = ctx.prep
+        csr_t, eid = prep.transposed()
+        drop = None if ctx.dropout is None or ctx.dropout[0] <= 0 else (ctx.dropout[0], ctx.dropout[1], eid)
+        dZ = csr_t.spmm(dY.contiguous(), coef=coef[eid.long()], dropout=drop)   # same mask: entry e of A^T carries edge id eid[e]
+        return dZ, None, None, None
 
 
 class LinearFn(torch.autograd.Function):

@@ -25,13 +25,36 @@ __device__ __forceinline__ f32x4 reduce_groups(f32x4 v) {
     return v;
 }
 
-template <int LPR>
+// Training-time dropout of the per-EDGE messages (the reference applies Dropout INSIDE the per-edge Linear, gnn_ncf.py:22-31,
+// 91-93: message_e = coef_e * dropout(W(x[src_e])), one mask element per (edge, feature)).  The mask is never stored: element
+// (edge id, feature) keeps iff a 16-bit slice of a counter-based hash of (seed, edge id, 16-byte chunk) reaches the threshold —
+// the forward pass (CSR by destination) and its transpose (CSR by source, edge ids through `eid`) regenerate the same mask.
+struct DropArgs {
+    const int32_t* eid;   // edge id of each CSR entry (NULL: the entry's own position)
+    uint32_t seed, thr;   // keep iff hash16 >= thr, thr = round(p * 65536)
+    float scale;          // 1 / (1 - thr / 65536)
+};
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // lowbias32 (bijective avalanche mix)
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ f32x4 drop4(f32x4 v, uint32_t edge, int chunk, const DropArgs& d) {
+    const uint32_t h0 = mix32(edge * 0x9E3779B1U ^ d.seed ^ (uint32_t)chunk * 0x85EBCA77U);
+    const uint32_t h1 = mix32(h0 ^ 0x68E31DA4U);
+    v[0] = (h0 & 0xFFFFU) >= d.thr ? v[0] * d.scale : 0.f;
+    v[1] = (h0 >> 16) >= d.thr ? v[1] * d.scale : 0.f;
+    v[2] = (h1 & 0xFFFFU) >= d.thr ? v[2] * d.scale : 0.f;
+    v[3] = (h1 >> 16) >= d.thr ? v[3] * d.scale : 0.f;
+    return v;
+}
+
+template <int LPR, bool DROP = false>
 __global__ __launch_bounds__(256) void spmm_seg_kernel(const int64_t* __restrict__ segptr, const int32_t* __restrict__ row_of,
                                                        int64_t n_seg, const int32_t* __restrict__ col,
                                                        const float* __restrict__ coef, const float* __restrict__ z,
                                                        int64_t Nz, int64_t ldz, int chunks, float* __restrict__ y,
                                                        int64_t ldy, float* __restrict__ sum, int64_t ldsum,
-                                                       float* __restrict__ partial) {
+                                                       float* __restrict__ partial, DropArgs drop = DropArgs{}) {
     constexpr int EPI = 64 / LPR;  // edges per wave-instruction
     constexpr int UNROLL = 4;
     const int lane = threadIdx.x & 63;
@@ -56,6 +79,7 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const int64_t* __restrict
                     if (src >= 0 && src < Nz) {
                         w[u] = coef ? coef[e] : 1.f;
                         v[u] = *reinterpret_cast<const f32x4*>(z + src * ldz + 4 * c);
+                        if (DROP) v[u] = drop4(v[u], (uint32_t)(drop.eid ? drop.eid[e] : e), c, drop);
                     }
                 }
             }
@@ -181,11 +205,15 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(const int64_t* __rest
 template <int LPR>
 static void launch_spmm(const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col, const float* coef,
                         const float* z, int64_t Nz, int64_t ldz, int chunks, float* y, int64_t ldy, float* sum, int64_t ldsum,
-                        float* partial, bool fixup, hipStream_t s) {
+                        float* partial, bool fixup, hipStream_t s, const DropArgs* drop = nullptr) {
     int64_t blocks = (n_seg + 3) / 4;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL((spmm_seg_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, s, segptr, row_of, n_seg, col, coef, z, Nz,
-                       ldz, chunks, y, ldy, sum, ldsum, partial);
+    if (drop)
+        hipLaunchKernelGGL((spmm_seg_kernel<LPR, true>), dim3((unsigned)blocks), dim3(256), 0, s, segptr, row_of, n_seg, col, coef, z, Nz,
+                           ldz, chunks, y, ldy, sum, ldsum, partial, *drop);
+    else
+        hipLaunchKernelGGL((spmm_seg_kernel<LPR, false>), dim3((unsigned)blocks), dim3(256), 0, s, segptr, row_of, n_seg, col, coef, z, Nz,
+                           ldz, chunks, y, ldy, sum, ldsum, partial, DropArgs{});
     if (row_of && fixup) {
         int64_t fb = (n_seg * LPR + 255) / 256;
         if (fb > 256 * 64) fb = 256 * 64;
@@ -197,26 +225,47 @@ static void launch_spmm(const int64_t* segptr, const int32_t* row_of, int64_t n_
 
 using namespace ncf;
 
-extern "C" int ncf_spmm_csr(int dtype, const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col,
-                            const float* coef, const void* z, int64_t Nz, int64_t ldz, int D, void* y, int64_t ldy,
-                            float* sum, int64_t ldsum, float* partial, int fixup, ncf_stream_t stream) {
-    if (dtype != NCF_F32) return fail(NCF_EUNSUPPORTED, "ncf_spmm_csr: fp32 only");
-    if (!segptr || !z || !y || n_seg < 0 || D <= 0) return fail(NCF_EINVAL, "ncf_spmm_csr: bad argument");
-    if (D % 4 || D > 256) return fail(NCF_EUNSUPPORTED, "ncf_spmm_csr: D = %d (need D %% 4 == 0 and D <= 256)", D);
+static int spmm_impl(const char* who, int dtype, const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col,
+                     const float* coef, const void* z, int64_t Nz, int64_t ldz, int D, void* y, int64_t ldy, float* sum, int64_t ldsum,
+                     float* partial, int fixup, const DropArgs* drop, ncf_stream_t stream) {
+    if (dtype != NCF_F32) return fail(NCF_EUNSUPPORTED, "%s: fp32 only", who);
+    if (!segptr || !z || !y || n_seg < 0 || D <= 0) return fail(NCF_EINVAL, "%s: bad argument", who);
+    if (D % 4 || D > 256) return fail(NCF_EUNSUPPORTED, "%s: D = %d (need D %% 4 == 0 and D <= 256)", who, D);
     if (ldz % 4 || ldy % 4 || (sum && ldsum % 4) || !aligned16(z) || !aligned16(y) || (sum && !aligned16(sum)) || (partial && !aligned16(partial)))
-        return fail(NCF_EINVAL, "ncf_spmm_csr: rows must be 16-byte aligned (ld %% 4 == 0)");
-    if (row_of && !partial && fixup) return fail(NCF_EINVAL, "ncf_spmm_csr: split rows need a partial buffer");
+        return fail(NCF_EINVAL, "%s: rows must be 16-byte aligned (ld %% 4 == 0)", who);
+    if (row_of && !partial && fixup) return fail(NCF_EINVAL, "%s: split rows need a partial buffer", who);
     if (n_seg == 0) return NCF_OK;
     // col may be null for an edgeless graph (every segment empty): the kernel dereferences it only inside a segment
     hipStream_t s = (hipStream_t)stream;
     const int chunks = D / 4;
     const float* zf = (const float*)z;
     float* yf = (float*)y;
-    if (chunks <= 8) launch_spmm<8>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s);
-    else if (chunks <= 16) launch_spmm<16>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s);
-    else if (chunks <= 32) launch_spmm<32>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s);
-    else launch_spmm<64>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s);
-    return check_launch("ncf_spmm_csr");
+    if (chunks <= 8) launch_spmm<8>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s, drop);
+    else if (chunks <= 16) launch_spmm<16>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s, drop);
+    else if (chunks <= 32) launch_spmm<32>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s, drop);
+    else launch_spmm<64>(segptr, row_of, n_seg, col, coef, zf, Nz, ldz, chunks, yf, ldy, sum, ldsum, partial, fixup != 0, s, drop);
+    return check_launch(who);
+}
+
+extern "C" int ncf_spmm_csr(int dtype, const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col,
+                            const float* coef, const void* z, int64_t Nz, int64_t ldz, int D, void* y, int64_t ldy,
+                            float* sum, int64_t ldsum, float* partial, int fixup, ncf_stream_t stream) {
+    return spmm_impl("ncf_spmm_csr", dtype, segptr, row_of, n_seg, col, coef, z, Nz, ldz, D, y, ldy, sum, ldsum, partial, fixup, nullptr, stream);
+}
+
+extern "C" int ncf_spmm_csr_dropout(int dtype, const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col,
+                                    const float* coef, const void* z, int64_t Nz, int64_t ldz, int D, void* y, int64_t ldy,
+                                    float* sum, int64_t ldsum, float* partial, int fixup, const int32_t* edge_id, uint32_t seed,
+                                    float p, ncf_stream_t stream) {
+    if (!(p >= 0.f && p < 1.f)) return fail(NCF_EINVAL, "ncf_spmm_csr_dropout: p = %g is not in [0, 1)", (double)p);
+    DropArgs d;
+    d.eid = edge_id;
+    d.seed = seed;
+    d.thr = (uint32_t)(p * 65536.f + 0.5f);
+    if (d.thr > 65535u) d.thr = 65535u;
+    d.scale = 65536.f / (float)(65536u - d.thr);
+    return spmm_impl("ncf_spmm_csr_dropout", dtype, segptr, row_of, n_seg, col, coef, z, Nz, ldz, D, y, ldy, sum, ldsum, partial, fixup,
+                     d.thr ? &d : nullptr, stream);
 }
 
 extern "C" int ncf_degree_accumulate(const int64_t* dst, int64_t E, int64_t N, float* deg, int32_t* oob, ncf_stream_t stream) {

@@ -46,6 +46,8 @@ SIGNATURES = {
                                  _c_int, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "ncf_spmm_csr": (_c_int, [_c_int, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p,
                               _c_i64, _c_p, _c_int, _c_p]),
+    "ncf_spmm_csr_dropout": (_c_int, [_c_int, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p,
+                                      _c_i64, _c_p, _c_int, _c_p, ctypes.c_uint32, ctypes.c_float, _c_p]),
     "ncf_degree_accumulate": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "ncf_edge_coef": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_scale_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, ctypes.c_float, _c_p, _c_i64, _c_p]),
@@ -360,7 +362,8 @@ def score_fused(tabA: torch.Tensor, idxA, tabB: Optional[torch.Tensor], idxB, pa
 # ------------------------------------------------------------------ K4 / K5
 def spmm_csr(segptr: torch.Tensor, row_of: Optional[torch.Tensor], col: torch.Tensor, coef: Optional[torch.Tensor],
              z: torch.Tensor, N: int, y: Optional[torch.Tensor] = None, acc_sum: Optional[torch.Tensor] = None,
-             partial: Optional[torch.Tensor] = None, fixup: bool = True) -> torch.Tensor:
+             partial: Optional[torch.Tensor] = None, fixup: bool = True, dropout: Optional[tuple] = None) -> torch.Tensor:
+    """``dropout`` = (p, seed, edge_id or None): per-(edge, feature) message dropout regenerated in the kernel (training)."""
     lib = load_library()
     _dev(z, "z")
     Nz, D, ldz = _rows2d(z, "z")
@@ -373,6 +376,14 @@ def spmm_csr(segptr: torch.Tensor, row_of: Optional[torch.Tensor], col: torch.Te
         y = torch.empty((N, D), dtype=torch.float32, device=z.device)
     if row_of is not None and partial is None:
         partial = torch.empty((n_seg, D), dtype=torch.float32, device=z.device)
+    if dropout is not None and dropout[0] > 0:
+        p, seed, eid = dropout
+        if eid is not None and (eid.dtype != torch.int32 or eid.numel() != col.numel()):
+            raise TypeError("edge ids must be int32, one per CSR entry")
+        _check(lib.ncf_spmm_csr_dropout(NCF_F32, _ptr(segptr), _ptr(row_of), n_seg, _ptr(col), _ptr(coef), _ptr(z), Nz, ldz, D, _ptr(y),
+                                        y.stride(0), _ptr(acc_sum), 0 if acc_sum is None else acc_sum.stride(0), _ptr(partial),
+                                        1 if fixup else 0, _ptr(eid), int(seed) & 0xFFFFFFFF, float(p), _stream(z)))
+        return y
     _check(lib.ncf_spmm_csr(NCF_F32, _ptr(segptr), _ptr(row_of), n_seg, _ptr(col), _ptr(coef), _ptr(z), Nz, ldz, D, _ptr(y),
                             y.stride(0), _ptr(acc_sum), 0 if acc_sum is None else acc_sum.stride(0), _ptr(partial),
                             1 if fixup else 0, _stream(z)))
@@ -433,20 +444,21 @@ class SegmentedCSR:
         self._partials = {}
 
     def spmm(self, z: torch.Tensor, y: Optional[torch.Tensor] = None, acc_sum: Optional[torch.Tensor] = None,
-             coef: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``coef`` overrides the per-edge coefficients for this call (LightGAT recomputes them every layer)."""
+             coef: Optional[torch.Tensor] = None, dropout: Optional[tuple] = None) -> torch.Tensor:
+        """``coef`` overrides the per-edge coefficients for this call (LightGAT recomputes them every layer; a training step
+        masks target edges).  ``dropout`` = (p, seed, edge_id or None): message dropout at the edge level (see spmm_csr)."""
         D = z.shape[1]
         coef = self.coef if coef is None else coef
         segptr, row_of, _ = self.levels[0]
         if y is None:
             y = torch.empty((self.n_rows, D), dtype=torch.float32, device=z.device)
         if len(self.levels) == 1:
-            return spmm_csr(segptr, row_of, self.col, coef, z, self.n_rows, y=y, acc_sum=acc_sum)
+            return spmm_csr(segptr, row_of, self.col, coef, z, self.n_rows, y=y, acc_sum=acc_sum, dropout=dropout)
         bufs = self._partials.get(D)
         if bufs is None:
             bufs = [torch.empty((lv[0].numel() - 1, D), dtype=torch.float32, device=z.device) for lv in self.levels[:-1]]
             self._partials[D] = bufs
-        spmm_csr(segptr, row_of, self.col, coef, z, self.n_rows, y=y, acc_sum=acc_sum, partial=bufs[0], fixup=False)
+        spmm_csr(segptr, row_of, self.col, coef, z, self.n_rows, y=y, acc_sum=acc_sum, partial=bufs[0], fixup=False, dropout=dropout)
         for li in range(1, len(self.levels)):
             segptr, row_of, edge_ids = self.levels[li]
             last = li == len(self.levels) - 1

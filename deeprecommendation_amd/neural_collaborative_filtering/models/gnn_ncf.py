@@ -133,7 +133,50 @@ class PreparedGraph:
         # rows longer than seg_len are split into segments; hub rows are finished by an ordered log-depth tree
         self.csr = native.SegmentedCSR(rowptr, self.col, self.coef, seg_len=seg_len)
         self.segptr, self.row_of = self.csr.levels[0][0], self.csr.levels[0][1]
+        self.counts = counts
+        self._seg_len = seg_len
+        self._transposed = None
+        self._train = None
+        self._edges = (u2i, i2u)          # references only: the training step derives its per-edge keys on first use
         native.check_oob(dev)
+
+    def transposed(self):
+        """(CSR by SOURCE, edge ids): entry k of the transpose is entry eid[k] of the CSR by destination — the backward of the
+        aggregation, dz[src] += coef_e * dy[dst], is the same segmented SpMM on it.  Built on first use (training only)."""
+        if self._transposed is None:
+            dst_of = torch.repeat_interleave(torch.arange(self.N, device=self.col.device), self.counts)
+            order = torch.argsort(self.col, stable=True)
+            counts_t = torch.bincount(self.col.long(), minlength=self.z_rows)
+            rowptr_t = torch.zeros(self.z_rows + 1, dtype=torch.int64, device=self.col.device)
+            rowptr_t[1:] = torch.cumsum(counts_t, 0)
+            eid = order.to(torch.int32).contiguous()
+            csr_t = native.SegmentedCSR(rowptr_t, dst_of[order].to(torch.int32).contiguous(), None, seg_len=self._seg_len)
+            self._transposed = (csr_t, eid)
+        return self._transposed
+
+    def train_state(self):
+        """Per-graph tensors of the training step, built on first use: destination and source of every CSR entry and its
+        (user, item) key for the target-edge masking (gnn_ncf.py:314-320, 369-378)."""
+        if self._train is None:
+            u2i, i2u = self._edges
+            order = torch.argsort(torch.cat([u2i[1], i2u[1]]), stable=True)     # the CSR's own order (see __init__)
+            pair_key = torch.cat([u2i[0] * self.N + u2i[1], i2u[1] * self.N + i2u[0]])[order]
+            dst_of = torch.repeat_interleave(torch.arange(self.N, device=self.col.device), self.counts)
+            self._train = (dst_of, self.col.long(), pair_key)
+        return self._train
+
+    def masked_coef(self, user_ids, item_ids):
+        """Coefficients of one training batch with the batch's target edges removed in both directions (gnn_ncf.py:314-320):
+        the degrees are those of the REMAINING edges (the reference recomputes them from the masked edge lists, :47-50), a
+        removed edge gets coefficient 0 — the CSR itself stays as it is."""
+        dst_of, src, pair_key = self.train_state()
+        masked = torch.isin(pair_key, user_ids.long() * self.N + item_ids.long())
+        deg = (self.counts - torch.bincount(dst_of[masked], minlength=self.N)).to(torch.float32)
+        dis = deg.pow(-0.5)
+        dis[dis == float('inf')] = 0
+        norm = dis[src] * dis[dst_of]
+        coef = norm if self.attr is None else self.attr * norm
+        return torch.where(masked, torch.zeros_like(coef), coef).contiguous()
 
 
 class _ConvBase(nn.Module):
@@ -373,7 +416,58 @@ class GraphNCF(_ScoringMixin, GNN_NCF):
     def _drop_edges(keep, ei, attr):
         return ei[:, keep], (attr[keep] if attr is not None else None)
 
+    def _hip_training_possible(self, graph, userIds) -> bool:
+        """The training step runs on the HIP autograd blocks for LightGCN layers on CUDA tensors; node / message dropout (edge
+        sets redrawn per batch on the host, gnn_ncf.py:246-296) and LightGAT keep to the torch ops, as do hetero graphs whose
+        sources are not split items / users (two stacked hoisted tables)."""
+        return (userIds.is_cuda and not getattr(self, "train_with_torch_ops", False) and self.convType == 'LightGCN'
+                and not (self.training and ((self.node_dropout or 0.0) > 0.0 or (self.message_dropout or 0.0) > 0.0)))
+
+    def _forward_train_hip(self, graph, userIds, itemIds, mask_targets):
+        """gnn_ncf.py:298-367 with autograd recording, on the HIP blocks: per-node hoisted Linear (LinearFn), aggregation
+        (SpmmFn, with the per-edge message dropout of gnn_ncf.py:22-31 regenerated inside the kernel), row gather + MLP."""
+        from ...autograd import GatherConcatFn, LinearFn, SpmmFn, mlp_train
+        dev = userIds.device
+        graph = graph.to(dev)
+        pk = ("prep", self.hetero)
+        if pk not in graph._prepared:
+            graph._prepared[pk] = PreparedGraph(graph, self.hetero)
+        prep = graph._prepared[pk]
+        if prep.z_rows != prep.N:
+            return None                                    # stacked hoisted tables: torch path
+        I = graph.num_items
+
+        def feats(f, lin):
+            if f is None:                                  # one-hot identity features: Linear(eye) = W^T + b
+                return lin.weight.t() + lin.bias
+            return LinearFn.apply(f.float(), lin.weight, lin.bias, False)
+
+        x = torch.vstack([feats(graph.item_features, self.item_embeddings[0]), feats(graph.user_features, self.user_embeddings[0])])
+        userIds, itemIds = userIds.long().contiguous(), itemIds.long().contiguous()
+        coef = prep.masked_coef(userIds, itemIds) if (self.training and mask_targets) else prep.coef
+        conv = self.gnn_convs[0]
+        p = float((conv.W if not conv.hetero else conv.user2item_W)[1].p) if self.training else 0.0
+        seed0 = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0     # host generator: no device sync
+        hs = [x]
+        for layer in range(len(self.gnn_convs)):
+            if not conv.hetero:
+                z = LinearFn.apply(x, conv.W[0].weight, conv.W[0].bias, False)
+            else:                                          # rows [0, I) are item sources (item2user_W), the rest user sources
+                z = torch.cat((LinearFn.apply(x[:I], conv.item2user_W[0].weight, conv.item2user_W[0].bias, False),
+                               LinearFn.apply(x[I:], conv.user2item_W[0].weight, conv.user2item_W[0].bias, False)), dim=0)
+            x = SpmmFn.apply(z, prep, coef, (p, seed0 + 7919 * layer) if p > 0 else None)
+            hs.append(x)
+        combined = torch.cat(hs, dim=1) if self.concat else torch.mean(torch.stack(hs, dim=0), dim=0)
+        if self.MLP is not None:
+            return mlp_train(self.MLP, GatherConcatFn.apply(combined, itemIds, combined, userIds))   # cat(item, user): :361
+        item_emb, user_emb = combined[itemIds], combined[userIds]
+        return torch.bmm(user_emb.unsqueeze(1), item_emb.unsqueeze(2)).view(-1, 1)
+
     def _forward_train(self, graph, userIds, itemIds, device, mask_targets):
+        if self._hip_training_possible(graph, userIds):
+            out = self._forward_train_hip(graph, userIds, itemIds, mask_targets)
+            if out is not None:
+                return out
         dev = userIds.device
         graph = graph.to(dev)
         x = torch.vstack([self._features(graph.item_features, self.item_embeddings[0]),

@@ -192,6 +192,21 @@ int ncf_spmm_csr(int dtype, const int64_t* dev_segptr, const int32_t* dev_row_of
                  void* dev_y, int64_t ldy, float* dev_sum, int64_t ldsum,
                  float* dev_partial, int fixup, ncf_stream_t stream);
 
+/* Training-step form of ncf_spmm_csr: the reference applies Dropout INSIDE the per-edge Linear of a LightGCN layer
+ * (gnn_ncf.py:22-31, 91-93: message_e = coef_e * dropout_p(W(x[src_e])), one mask element per (edge, feature), kept values
+ * scaled by 1 / (1 - p)), which a per-node hoisted Linear cannot express.  Here the mask is regenerated inside the kernel from a
+ * counter-based hash of (seed, edge id, feature): element (e, f) of the mask is a pure function of the three, so
+ *   forward   y  = sum_e coef_e * mask(id_e, :) / (1 - p') * z[col_e]        (CSR by destination, dev_edge_id = NULL: id = position)
+ *   backward  dz = the same call on the CSR by SOURCE with dev_edge_id[.] = each entry's position in the forward CSR
+ * use the same mask without storing it.  p' = round(p * 65536) / 65536 (the keep test is on 16 hash bits).  The masks are
+ * NOT torch's Philox stream: a seeded run differs from the reference's in the (random) masks drawn, not in their law.
+ * Only edge-level calls take a mask (the partial-sum tree levels of split rows go through ncf_spmm_csr).  p = 0: ncf_spmm_csr. */
+int ncf_spmm_csr_dropout(int dtype, const int64_t* dev_segptr, const int32_t* dev_row_of, int64_t n_seg,
+                         const int32_t* dev_col, const float* dev_coef,
+                         const void* dev_z, int64_t Nz, int64_t ldz, int D,
+                         void* dev_y, int64_t ldy, float* dev_sum, int64_t ldsum,
+                         float* dev_partial, int fixup, const int32_t* dev_edge_id, uint32_t seed, float p, ncf_stream_t stream);
+
 /* deg[n] = number of edges whose destination is n (float, exact below 2^24) — PyG degree(), gnn_ncf.py:48.
  * dev_deg must be zero-filled by the caller; two calls (u2i, i2u) accumulate into the same array, which is
  * the cat at gnn_ncf.py:41. */

@@ -378,3 +378,111 @@ def test_fused_adam_invalidates_the_scoring_caches(gpu):
         opt.zero_grad(set_to_none=True)
         torch.nn.functional.mse_loss(m(u, i), y, reduction="sum").backward()
         opt.step()
+
+
+# ----------------------------------------------------------------------------- GraphNCF training step on the HIP blocks
+def _train_graph(n_items, n_users, n_inter, seed, binary=False):
+    g = torch.Generator().manual_seed(seed)
+    key = torch.unique(torch.randint(0, n_users, (n_inter,), generator=g) * n_items + (torch.rand(n_inter, generator=g) ** 2 * n_items).long())
+    u, i = key // n_items + n_items, key % n_items
+    a = None if binary else torch.randn(u.numel(), generator=g)
+    return torch.stack([u, i]), torch.stack([i, u]), a
+
+
+@pytest.mark.parametrize("hetero", [True, False])
+@pytest.mark.parametrize("binary,concat,dot", [(False, False, False), (True, True, False), (False, False, True)])
+@pytest.mark.parametrize("mask_targets", [True, False])
+def test_graph_ncf_training_step_gradients(gpu, hetero, binary, concat, dot, mask_targets):
+    """GraphNCF training step (gnn_ncf.py:298-367 under autograd, train.py:95-110) on the HIP blocks — hoisted Linear,
+    SpMM forward, SpMM^T backward on the CSR by source, row gather / scatter, MLP — against the same model run with torch ops
+    on the CPU: loss and every parameter gradient, incl. the batch's target edges masked out of both directions with the
+    degrees recomputed.  Dropout off (the masks are RNG-dependent: see the adjoint test below for the fused message dropout)."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphData, GraphNCF
+    n_items, n_users, D, B = 40, 300, 64, 256
+    u2i, i2u, a = _train_graph(n_items, n_users, 4000, seed=3, binary=binary)
+    torch.manual_seed(5)
+    m_cpu = GraphNCF(item_dim=n_items, user_dim=n_users, num_gnn_layers=2, hetero=hetero, node_emb=D, mlp_dense_layers=[128],
+                     dropout_rate=0.0, concat=concat, use_dot_product=dot).train()
+    m_gpu = copy.deepcopy(m_cpu).to(gpu).train()
+    g = torch.Generator().manual_seed(6)
+    pick = torch.randint(0, u2i.shape[1], (B,), generator=g)         # batch pairs that ARE edges: the masking has work to do
+    users, items = u2i[0][pick], u2i[1][pick]
+    y = torch.rand(B, 1, generator=g) * 5
+
+    def graph(dev):
+        return GraphData(user2item_edge_index=u2i.to(dev), item2user_edge_index=i2u.to(dev), user2item_edge_attr=None if a is None else a.to(dev),
+                         item2user_edge_attr=None if a is None else a.clone().to(dev), num_items=n_items, num_users=n_users)
+
+    out_c = m_cpu(graph("cpu"), users, items, "cpu", mask_targets)
+    loss_c = torch.nn.functional.mse_loss(out_c, y, reduction="sum")
+    loss_c.backward()
+    out_g = m_gpu(graph(gpu), users.to(gpu), items.to(gpu), gpu, mask_targets)
+    assert out_g.requires_grad
+    loss_g = torch.nn.functional.mse_loss(out_g, y.to(gpu), reduction="sum")
+    loss_g.backward()
+    assert abs(float(loss_g) - float(loss_c)) <= 2e-5 * abs(float(loss_c))
+    _grads_close(m_gpu, m_cpu, rtol=5e-5)
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_spmm_message_dropout_is_adjoint_and_unbiased(gpu, p):
+    """Fused per-(edge, feature) message dropout (ncf_spmm_csr_dropout): the forward on the CSR by destination and the
+    backward on the CSR by source regenerate the SAME mask — <A_mask z, g> == <z, A_mask^T g> to fp32 rounding — the kept
+    fraction is 1 - p, kept values are scaled by 1 / (1 - p'), another seed gives another mask, p = 0 is the plain SpMM."""
+    from deeprecommendation_amd.autograd import SpmmFn
+    from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphData, PreparedGraph
+    n_items, n_users, D = 50, 2000, 128
+    u2i, i2u, a = _train_graph(n_items, n_users, 60000, seed=8)     # hub items: split rows + partial-sum tree in both directions
+    graph = GraphData(user2item_edge_index=u2i.to(gpu), item2user_edge_index=i2u.to(gpu), user2item_edge_attr=a.to(gpu),
+                      item2user_edge_attr=a.clone().to(gpu), num_items=n_items, num_users=n_users)
+    prep = PreparedGraph(graph, hetero=False, seg_len=64)
+    N = n_items + n_users
+    gen = torch.Generator(device=gpu).manual_seed(1)
+    z = torch.randn(N, D, device=gpu, generator=gen).requires_grad_(True)
+    gy = torch.randn(N, D, device=gpu, generator=gen)
+    y = SpmmFn.apply(z, prep, prep.coef, (p, 1234))
+    (dz,) = torch.autograd.grad(y, z, gy)
+    lhs, rhs = float((y.double() * gy.double()).sum()), float((z.detach().double() * dz.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+    again = SpmmFn.apply(z, prep, prep.coef, (p, 1234))
+    assert torch.equal(y, again)                                     # same seed, same mask, same order: bitwise
+    other = SpmmFn.apply(z, prep, prep.coef, (p, 99))
+    assert not torch.equal(y, other)
+    # unbiased: with z = 1 and coef = 1, y[n, f] / deg[n] is the kept fraction / (1 - p') -> 1
+    ones = torch.ones(N, D, device=gpu)
+    cnt = SpmmFn.apply(ones, prep, torch.ones_like(prep.coef), (p, 7)).sum() / (prep.col.numel() * D)
+    assert abs(float(cnt) - 1.0) < 5e-3
+    kept = SpmmFn.apply(ones, prep, torch.ones_like(prep.coef), (p, 7))
+    thr = round(p * 65536)
+    scale = 65536.0 / (65536 - thr)
+    assert bool(((kept / scale - (kept / scale).round()).abs() < 1e-3).all())    # every destination sums whole kept entries
+    plain = prep.csr.spmm(z.detach())
+    assert torch.equal(SpmmFn.apply(z.detach(), prep, prep.coef, None), plain)
+
+
+def test_graph_ncf_trains_with_message_dropout_on_hip_blocks(gpu):
+    """Default hyper-parameters (dropout_rate 0.2 -> per-edge message dropout 0.1 inside the conv, gnn_ncf.py:218) on the HIP
+    blocks + FusedAdam: the loss goes down, and the eval-mode HIP scoring follows the updated weights."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphData, GraphNCF
+    from deeprecommendation_amd.optim import FusedAdam
+    n_items, n_users, D = 40, 400, 64
+    u2i, i2u, a = _train_graph(n_items, n_users, 6000, seed=11)
+    graph = GraphData(user2item_edge_index=u2i.to(gpu), item2user_edge_index=i2u.to(gpu), user2item_edge_attr=a.to(gpu),
+                      item2user_edge_attr=a.clone().to(gpu), num_items=n_items, num_users=n_users)
+    torch.manual_seed(0)
+    m = GraphNCF(item_dim=n_items, user_dim=n_users, num_gnn_layers=2, hetero=True, node_emb=D, mlp_dense_layers=[128]).to(gpu).train()
+    opt = FusedAdam(m.parameters(), lr=3e-3)
+    users, items = u2i[0].to(gpu), u2i[1].to(gpu)
+    y = (a.to(gpu) + 2.5).view(-1, 1)
+    losses = []
+    for step in range(30):
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(m(graph, users, items, gpu, True), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.7 * losses[0], losses[::5]
+    m.eval()
+    with torch.no_grad():
+        s1 = m(graph, users[:64], items[:64], gpu)
+    assert torch.isfinite(s1).all()
