@@ -141,6 +141,33 @@ class SpmmFn(torch.autograd.Function):
         return dZ, None, None, None
 
 
+class AttnFn(torch.autograd.Function):
+    """user_emb (B, UE) = bias + sum_e softmax_e(score(b, e)) * val_e * proj[col_e, :]  —  attention_ncf.py:176-216 for one CSR row
+    of rated entries per pair, forward (ncf_attn_forward / _dropout) and backward (ncf_attn_backward) on the HIP kernels.
+    ``b1`` (AttentionNet's output bias) is taken only to hand it its gradient, which is exactly zero: a shift of every score
+    cancels in the softmax.  ``dropout`` = (p, seed) or None: AttentionNet's hidden dropout, regenerated in both kernels."""
+
+    @staticmethod
+    def forward(ctx, pc, pr, w1, b1, proj, bias, rowptr, col, val, mode, dropout):
+        pc, pr, proj = pc.contiguous(), pr.contiguous(), proj.contiguous()
+        w1c = None if w1 is None else w1.contiguous()
+        out, wts = native.attn_forward(mode, pc, pr, w1c, 0.0, rowptr, col, val, proj, out_bias=bias, dropout=dropout)
+        ctx.mode, ctx.dropout = mode, dropout
+        ctx.has = (w1 is not None, b1 is not None, bias is not None)
+        ctx.save_for_backward(pc, pr, w1c, proj, rowptr, col, val, wts)
+        ctx.mark_non_differentiable(wts)
+        return out, wts
+
+    @staticmethod
+    def backward(ctx, dout, _dwts):
+        pc, pr, w1c, proj, rowptr, col, val, wts = ctx.saved_tensors
+        d_pc, d_pr, d_w1, d_proj = native.attn_backward(ctx.mode, pc, pr, w1c, rowptr, col, val, proj, wts, dout, dropout=ctx.dropout)
+        has_w1, has_b1, has_bias = ctx.has
+        d_b1 = torch.zeros(1, dtype=torch.float32, device=dout.device) if has_b1 else None
+        d_bias = native.colsum(dout.contiguous()) if has_bias else None
+        return d_pc, d_pr, (d_w1 if has_w1 else None), d_b1, d_proj, d_bias, None, None, None, None, None
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu):

@@ -95,15 +95,33 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
 }
 
+// Training-time dropout of AttentionNet's hidden layer (attention_ncf.py:112-117: Linear, ReLU, Dropout, Linear — one mask element
+// per (pair, rated entry, hidden unit)).  Never stored: element (entry e, units 4c..4c+3) keeps iff a 16-bit slice of a
+// counter-based hash of (seed, e, c) reaches the threshold; the backward kernel regenerates the same mask.
+struct AttDrop {
+    uint32_t seed, thr;   // keep iff hash16 >= thr, thr = round(p * 65536)
+    float scale;          // 1 / (1 - thr / 65536)
+};
+__device__ __forceinline__ uint32_t att_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ f32x4 att_mask4(uint32_t entry, int chunk, const AttDrop& d) {   // 0 or 1/(1-p') per element
+    const uint32_t h0 = att_mix32(entry * 0x9E3779B1U ^ d.seed ^ (uint32_t)chunk * 0x85EBCA77U);
+    const uint32_t h1 = att_mix32(h0 ^ 0x68E31DA4U);
+    return f32x4{(h0 & 0xFFFFU) >= d.thr ? d.scale : 0.f, (h0 >> 16) >= d.thr ? d.scale : 0.f,
+                 (h1 & 0xFFFFU) >= d.thr ? d.scale : 0.f, (h1 >> 16) >= d.thr ? d.scale : 0.f};
+}
+
 // MODE 0: MLP (relu + w1 dot), 1: linear (A == 1, pc + pr), 2: cosine (dot of normalised rows)
-template <int MODE>
+template <int MODE, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ pc, int64_t ldpc, const float* __restrict__ pr,
                                                    int64_t ldpr, int A, const float* __restrict__ w1, float b1,
                                                    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                    const float* __restrict__ val, int64_t B, int64_t I,
                                                    const float* __restrict__ feat, int64_t ldfeat, int Fdim,
                                                    const float* __restrict__ out_bias, float* __restrict__ out,
-                                                   int64_t ldout, float* __restrict__ wts) {
+                                                   int64_t ldout, float* __restrict__ wts, AttDrop drop = AttDrop{}) {
     const int lane = threadIdx.x & 63;
     // XCD-aware block order: hardware deals blocks round-robin over the 8 XCDs (b and b+8 share one), so logical block
     // L = (b % 8) * ceil(n/8) + b / 8 (bijective form) puts CONSECUTIVE pair groups on the same XCD.  Batches are
@@ -158,7 +176,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ pc,
                 for (int u = 0; u < U; ++u) {
                     const int64_t e = e0 + u * EPI + eg;
                     float part = 0.f;
-                    if (MODE == 0) {
+                    if (MODE == 0 && DROP) {
+                        const f32x4 mk = att_mask4((uint32_t)e, c, drop);
+                        part = fmaf(wv[0], fmaxf(pcv[0] + r[u][0], 0.f) * mk[0], part);
+                        part = fmaf(wv[1], fmaxf(pcv[1] + r[u][1], 0.f) * mk[1], part);
+                        part = fmaf(wv[2], fmaxf(pcv[2] + r[u][2], 0.f) * mk[2], part);
+                        part = fmaf(wv[3], fmaxf(pcv[3] + r[u][3], 0.f) * mk[3], part);
+                    } else if (MODE == 0) {
                         part = fmaf(wv[0], fmaxf(pcv[0] + r[u][0], 0.f), part);
                         part = fmaf(wv[1], fmaxf(pcv[1] + r[u][1], 0.f), part);
                         part = fmaf(wv[2], fmaxf(pcv[2] + r[u][2], 0.f), part);
@@ -268,6 +292,126 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ pc,
         }
     }
     (void)nnz;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K3 backward (training step; the reference differentiates attention_ncf.py:176-216 through autograd).  One wave per pair b,
+// given the forward's attention weights p_e (`wts`) and dOut[b, :]:
+//   dpv_e   = val_e * <dOut[b,:], feat[i_e,:]>                      d feat[i_e,:] += p_e val_e dOut[b,:]        (float atomics)
+//   ds_e    = p_e (dpv_e - sum_e' p_e' dpv_e')                      (softmax backward; sum_e ds_e = 0, so d b1 = 0 exactly)
+//   MLP:    u = pc[b,:] + pr[i_e,:],  h = relu(u) * mask            d w1 += ds_e h   (per-pair partial rows, summed by ncf_colsum)
+//           g = ds_e * w1 * [u > 0] * mask                          d pc[b,:] += g (registers),  d pr[i_e,:] += g (float atomics)
+//   cosine: d pc[b,:] += ds_e pr[i_e,:],  d pr[i_e,:] += ds_e pc[b,:]
+// A % 4 == 0, Fdim % 4 == 0, both <= 256.  `ds` (nnz floats) is scratch.  Atomic adds make d pr / d feat order-dependent in the
+// last bits, like ncf_scatter_add_rows.
+template <int MODE, bool DROP>
+__global__ __launch_bounds__(256) void attn_backward_kernel(const float* __restrict__ pc, int64_t ldpc, const float* __restrict__ pr,
+                                                            int64_t ldpr, int A, const float* __restrict__ w1,
+                                                            const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                            const float* __restrict__ val, int64_t B, int64_t I,
+                                                            const float* __restrict__ feat, int64_t ldfeat, int Fdim,
+                                                            const float* __restrict__ wts, const float* __restrict__ dout, int64_t lddout,
+                                                            float* __restrict__ d_pc, int64_t ldd_pc, float* __restrict__ d_pr, int64_t ldd_pr,
+                                                            float* __restrict__ d_w1_part, float* __restrict__ d_feat, int64_t ldd_feat,
+                                                            float* __restrict__ ds, AttDrop drop) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;  // wave-uniform
+    const int64_t beg = rowptr[b], end = rowptr[b + 1];
+    // ---- phase 1: dpv_e, the softmax-weighted mean t, and the feature-table gradient ----
+    {
+        const int chunks = Fdim / 4;
+        int LPF = 8;
+        while (LPF < chunks) LPF <<= 1;
+        const int c = lane % LPF, eg = lane / LPF, EPI = 64 / LPF;
+        const bool active = c < chunks;
+        f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+        if (active) dv = *reinterpret_cast<const f32x4*>(dout + b * lddout + 4 * c);
+        float tsum = 0.f;
+        for (int64_t e0 = beg; e0 < end; e0 += EPI) {
+            const int64_t e = e0 + eg;
+            float part = 0.f, pe = 0.f, ve = 0.f;
+            int64_t i = -1;
+            if (e < end) {
+                i = col[e];
+                if (i >= 0 && i < I) { pe = wts[e]; ve = val[e]; } else i = -1;
+            }
+            if (i >= 0 && active) {
+                const f32x4 f = *reinterpret_cast<const f32x4*>(feat + i * ldfeat + 4 * c);
+                part = fmaf(dv[0], f[0], fmaf(dv[1], f[1], fmaf(dv[2], f[2], dv[3] * f[3])));
+                const float a = pe * ve;
+                float* g = d_feat + i * ldd_feat + 4 * c;
+                atomicAdd(g + 0, a * dv[0]); atomicAdd(g + 1, a * dv[1]); atomicAdd(g + 2, a * dv[2]); atomicAdd(g + 3, a * dv[3]);
+            }
+            for (int off = 1; off < LPF; off <<= 1) part += __shfl_xor(part, off);
+            const float dpv = part * ve;
+            if (e < end && c == 0) { ds[e] = dpv; tsum += pe * dpv; }
+        }
+        tsum = wave_sum(tsum);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // other lanes of this wave read what this lane stored
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t e = beg + lane; e < end; e += 64) {
+            const int64_t i = col[e];
+            ds[e] = (i >= 0 && i < I) ? wts[e] * (ds[e] - tsum) : 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- phase 2: back through the score ----
+    {
+        const int chunks = A / 4;
+        int LPA = 8;
+        while (LPA < chunks) LPA <<= 1;
+        const int c = lane % LPA, eg = lane / LPA, EPI = 64 / LPA;
+        const bool active = c < chunks;
+        f32x4 pcv = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            pcv = *reinterpret_cast<const f32x4*>(pc + b * ldpc + 4 * c);
+            if (MODE == 0) wv = *reinterpret_cast<const f32x4*>(w1 + 4 * c);
+        }
+        f32x4 dpc = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t e0 = beg; e0 < end; e0 += EPI) {
+            const int64_t e = e0 + eg;
+            if (e < end && active) {
+                const int64_t i = col[e];
+                if (i >= 0 && i < I) {
+                    const float dse = ds[e];
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(pr + i * ldpr + 4 * c);
+                    f32x4 g;
+                    if (MODE == 0) {
+                        f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+                        if (DROP) mk = att_mask4((uint32_t)e, c, drop);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float u = pcv[j] + r[j];
+                            dw[j] = fmaf(dse, fmaxf(u, 0.f) * mk[j], dw[j]);
+                            g[j] = u > 0.f ? dse * wv[j] * mk[j] : 0.f;
+                            dpc[j] += g[j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            dpc[j] = fmaf(dse, r[j], dpc[j]);
+                            g[j] = dse * pcv[j];
+                        }
+                    }
+                    float* gp = d_pr + i * ldd_pr + 4 * c;
+                    atomicAdd(gp + 0, g[0]); atomicAdd(gp + 1, g[1]); atomicAdd(gp + 2, g[2]); atomicAdd(gp + 3, g[3]);
+                }
+            }
+        }
+        for (int off = LPA; off < 64; off <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dpc[j] += __shfl_xor(dpc[j], off);
+                dw[j] += __shfl_xor(dw[j], off);
+            }
+        }
+        if (eg == 0 && active) {
+            *reinterpret_cast<f32x4*>(d_pc + b * ldd_pc + 4 * c) = dpc;
+            if (MODE == 0) *reinterpret_cast<f32x4*>(d_w1_part + b * (int64_t)A + 4 * c) = dw;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1070,29 +1214,91 @@ extern "C" int ncf_l2_normalize_rows(const float* x, int64_t ldx, int64_t R, int
     return check_launch("ncf_l2_normalize_rows");
 }
 
+static int attn_forward_impl(const char* who, int mode, const float* pc, int64_t ldpc, const float* pr, int64_t ldpr, int A,
+                             const float* w1, float b1, const int64_t* rowptr, const int32_t* col, const float* val,
+                             int64_t B, int64_t I, const float* feat, int64_t ldfeat, int Fdim, const float* out_bias,
+                             float* out, int64_t ldout, float* wts, const AttDrop* drop, ncf_stream_t stream) {
+    if (mode < 0 || mode > 3) return fail(NCF_EINVAL, "%s: bad mode %d", who, mode);
+    if (mode == NCF_ATT_MLP_SCALED) mode = NCF_ATT_MLP;   // w' relu(p' + q') with exact power-of-two scales IS w relu(p + q): same kernel
+    if (B < 0 || I < 0 || A <= 0 || Fdim <= 0) return fail(NCF_EINVAL, "%s: bad sizes", who);
+    if (B == 0) return NCF_OK;
+    if (!pc || !pr || !rowptr || !feat || !out || !wts) return fail(NCF_EINVAL, "%s: null pointer", who);
+    if (mode == NCF_ATT_MLP && !w1) return fail(NCF_EINVAL, "%s: w1 is null", who);
+    if (mode == NCF_ATT_LINEAR && A != 1) return fail(NCF_EINVAL, "%s: linear mode needs A == 1", who);
+    if (ldpc < A || ldpr < A || ldfeat < Fdim || ldout < Fdim) return fail(NCF_EINVAL, "%s: leading dimension smaller than row", who);
+    if ((A % 4 == 0 && (!aligned16(pc) || !aligned16(pr) || (w1 && !aligned16(w1)))) ||
+        (Fdim % 4 == 0 && (!aligned16(feat) || !aligned16(out) || (out_bias && !aligned16(out_bias)))))
+        return fail(NCF_EINVAL, "%s: operands must be 16-byte aligned", who);
+    if (drop && (mode != NCF_ATT_MLP || A % 4 || A > 256 || ldpr % 4 || ldpc % 4))
+        return fail(NCF_EUNSUPPORTED, "%s: hidden-layer dropout needs the MLP mode with A %% 4 == 0, A <= 256", who);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((B + 3) / 4);
+#define LAUNCH(M) hipLaunchKernelGGL((attn_kernel<M, false>), dim3(blocks), dim3(256), 0, s, pc, ldpc, pr, ldpr, A, w1, b1, rowptr, col, val, B, I, feat, ldfeat, Fdim, out_bias, out, ldout, wts, AttDrop{})
+    if (drop) hipLaunchKernelGGL((attn_kernel<0, true>), dim3(blocks), dim3(256), 0, s, pc, ldpc, pr, ldpr, A, w1, b1, rowptr, col, val, B, I, feat, ldfeat, Fdim, out_bias, out, ldout, wts, *drop);
+    else if (mode == 0) LAUNCH(0);
+    else if (mode == 1) LAUNCH(1);
+    else LAUNCH(2);
+#undef LAUNCH
+    return check_launch(who);
+}
+
+static bool att_drop_args(float p, uint32_t seed, AttDrop& d) {
+    d.seed = seed;
+    d.thr = (uint32_t)(p * 65536.f + 0.5f);
+    if (d.thr > 65535u) d.thr = 65535u;
+    d.scale = 65536.f / (float)(65536u - d.thr);
+    return d.thr != 0;
+}
+
 extern "C" int ncf_attn_forward(int mode, const float* pc, int64_t ldpc, const float* pr, int64_t ldpr, int A,
                                 const float* w1, float b1, const int64_t* rowptr, const int32_t* col, const float* val,
                                 int64_t B, int64_t I, const float* feat, int64_t ldfeat, int Fdim, const float* out_bias,
                                 float* out, int64_t ldout, float* wts, ncf_stream_t stream) {
-    if (mode < 0 || mode > 3) return fail(NCF_EINVAL, "ncf_attn_forward: bad mode %d", mode);
-    if (mode == NCF_ATT_MLP_SCALED) mode = NCF_ATT_MLP;   // w' relu(p' + q') with exact power-of-two scales IS w relu(p + q): same kernel
-    if (B < 0 || I < 0 || A <= 0 || Fdim <= 0) return fail(NCF_EINVAL, "ncf_attn_forward: bad sizes");
+    return attn_forward_impl("ncf_attn_forward", mode, pc, ldpc, pr, ldpr, A, w1, b1, rowptr, col, val, B, I, feat, ldfeat, Fdim, out_bias,
+                             out, ldout, wts, nullptr, stream);
+}
+
+extern "C" int ncf_attn_forward_dropout(int mode, const float* pc, int64_t ldpc, const float* pr, int64_t ldpr, int A,
+                                        const float* w1, float b1, const int64_t* rowptr, const int32_t* col, const float* val,
+                                        int64_t B, int64_t I, const float* feat, int64_t ldfeat, int Fdim, const float* out_bias,
+                                        float* out, int64_t ldout, float* wts, uint32_t seed, float p, ncf_stream_t stream) {
+    if (!(p >= 0.f && p < 1.f)) return fail(NCF_EINVAL, "ncf_attn_forward_dropout: p = %g is not in [0, 1)", (double)p);
+    AttDrop d;
+    const bool on = att_drop_args(p, seed, d);
+    return attn_forward_impl("ncf_attn_forward_dropout", mode, pc, ldpc, pr, ldpr, A, w1, b1, rowptr, col, val, B, I, feat, ldfeat, Fdim,
+                             out_bias, out, ldout, wts, on ? &d : nullptr, stream);
+}
+
+extern "C" int ncf_attn_backward(int mode, const float* pc, int64_t ldpc, const float* pr, int64_t ldpr, int A, const float* w1,
+                                 const int64_t* rowptr, const int32_t* col, const float* val, int64_t B, int64_t I,
+                                 const float* feat, int64_t ldfeat, int Fdim, const float* wts, const float* dout, int64_t lddout,
+                                 float* d_pc, int64_t ldd_pc, float* d_pr, int64_t ldd_pr, float* d_w1_part, float* d_feat,
+                                 int64_t ldd_feat, float* ds, uint32_t seed, float p, ncf_stream_t stream) {
+    if (mode == NCF_ATT_MLP_SCALED) mode = NCF_ATT_MLP;
+    if (mode != NCF_ATT_MLP && mode != NCF_ATT_COS) return fail(NCF_EUNSUPPORTED, "ncf_attn_backward: mode %d (MLP and cosine only)", mode);
+    if (B < 0 || I < 0 || A <= 0 || Fdim <= 0) return fail(NCF_EINVAL, "ncf_attn_backward: bad sizes");
     if (B == 0) return NCF_OK;
-    if (!pc || !pr || !rowptr || !feat || !out || !wts) return fail(NCF_EINVAL, "ncf_attn_forward: null pointer");
-    if (mode == NCF_ATT_MLP && !w1) return fail(NCF_EINVAL, "ncf_attn_forward: w1 is null");
-    if (mode == NCF_ATT_LINEAR && A != 1) return fail(NCF_EINVAL, "ncf_attn_forward: linear mode needs A == 1");
-    if (ldpc < A || ldpr < A || ldfeat < Fdim || ldout < Fdim) return fail(NCF_EINVAL, "ncf_attn_forward: leading dimension smaller than row");
-    if ((A % 4 == 0 && (!aligned16(pc) || !aligned16(pr) || (w1 && !aligned16(w1)))) ||
-        (Fdim % 4 == 0 && (!aligned16(feat) || !aligned16(out) || (out_bias && !aligned16(out_bias)))))
-        return fail(NCF_EINVAL, "ncf_attn_forward: operands must be 16-byte aligned");
+    if (!pc || !pr || !rowptr || !feat || !wts || !dout || !d_pc || !d_pr || !d_feat || !ds || (mode == NCF_ATT_MLP && (!w1 || !d_w1_part)))
+        return fail(NCF_EINVAL, "ncf_attn_backward: null pointer");
+    if (A % 4 || Fdim % 4 || A > 256 || Fdim > 256 || ldpc % 4 || ldpr % 4 || ldfeat % 4 || lddout % 4 || ldd_pc % 4)
+        return fail(NCF_EUNSUPPORTED, "ncf_attn_backward: needs A, Fdim and the leading dimensions %% 4 == 0, A, Fdim <= 256");
+    if (ldpc < A || ldpr < A || ldfeat < Fdim || lddout < Fdim || ldd_pc < A || ldd_pr < A || ldd_feat < Fdim)
+        return fail(NCF_EINVAL, "ncf_attn_backward: leading dimension smaller than row");
+    if (!aligned16(pc) || !aligned16(pr) || (w1 && !aligned16(w1)) || !aligned16(feat) || !aligned16(dout) || !aligned16(d_pc) ||
+        (d_w1_part && !aligned16(d_w1_part)))
+        return fail(NCF_EINVAL, "ncf_attn_backward: operands must be 16-byte aligned");
+    if (!(p >= 0.f && p < 1.f)) return fail(NCF_EINVAL, "ncf_attn_backward: p = %g is not in [0, 1)", (double)p);
+    AttDrop d;
+    const bool on = att_drop_args(p, seed, d) && mode == NCF_ATT_MLP;
     hipStream_t s = (hipStream_t)stream;
     const unsigned blocks = (unsigned)((B + 3) / 4);
-#define LAUNCH(M) hipLaunchKernelGGL(attn_kernel<M>, dim3(blocks), dim3(256), 0, s, pc, ldpc, pr, ldpr, A, w1, b1, rowptr, col, val, B, I, feat, ldfeat, Fdim, out_bias, out, ldout, wts)
-    if (mode == 0) LAUNCH(0);
-    else if (mode == 1) LAUNCH(1);
-    else LAUNCH(2);
-#undef LAUNCH
-    return check_launch("ncf_attn_forward");
+#define LAUNCHB(M, D) hipLaunchKernelGGL((attn_backward_kernel<M, D>), dim3(blocks), dim3(256), 0, s, pc, ldpc, pr, ldpr, A, w1, rowptr, col, val, B, I, \
+                                         feat, ldfeat, Fdim, wts, dout, lddout, d_pc, ldd_pc, d_pr, ldd_pr, d_w1_part, d_feat, ldd_feat, ds, d)
+    if (mode == NCF_ATT_MLP && on) LAUNCHB(0, true);
+    else if (mode == NCF_ATT_MLP) LAUNCHB(0, false);
+    else LAUNCHB(2, false);
+#undef LAUNCHB
+    return check_launch("ncf_attn_backward");
 }
 
 extern "C" int ncf_attn_forward_grouped(int mode, const float* pc, int64_t ldpc, const float* pr, int64_t ldpr, int A,

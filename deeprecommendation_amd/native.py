@@ -53,6 +53,10 @@ SIGNATURES = {
     "ncf_scale_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, ctypes.c_float, _c_p, _c_i64, _c_p]),
     "ncf_attn_forward": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
                                   _c_i64, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "ncf_attn_forward_dropout": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
+                                          _c_i64, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32, ctypes.c_float, _c_p]),
+    "ncf_attn_backward": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_int,
+                                   _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32, ctypes.c_float, _c_p]),
     "ncf_attn_forward_grouped": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
                                           _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_int, _c_p, _c_p,
                                           _c_i64, _c_p, _c_p, _c_p]),
@@ -495,8 +499,8 @@ def scale_rows(x: torch.Tensor, divisor: float, out: Optional[torch.Tensor] = No
 # ------------------------------------------------------------------ K3
 def attn_forward(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[torch.Tensor], b1: float,
                  rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, feat: torch.Tensor,
-                 out_bias: Optional[torch.Tensor] = None):
-    """Returns (out_feat (B, Fdim), weights (nnz,))."""
+                 out_bias: Optional[torch.Tensor] = None, dropout: Optional[tuple] = None):
+    """Returns (out_feat (B, Fdim), weights (nnz,)).  ``dropout`` = (p, seed): AttentionNet's hidden dropout (training)."""
     lib = load_library()
     _dev(pc, "pc")
     B, A, ldpc = _rows2d(pc, "pc")
@@ -508,9 +512,35 @@ def attn_forward(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[tor
         raise TypeError("CSR must be (int64 rowptr, int32 col, fp32 val)")
     out = torch.empty((B, Fdim), dtype=torch.float32, device=pc.device)
     wts = torch.empty(max(col.numel(), 1), dtype=torch.float32, device=pc.device)
+    if dropout is not None and dropout[0] > 0:
+        _check(lib.ncf_attn_forward_dropout(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), float(b1), _ptr(rowptr), _ptr(col), _ptr(val),
+                                            B, I, _ptr(feat), ldf, Fdim, _ptr(out_bias), _ptr(out), out.stride(0), _ptr(wts),
+                                            int(dropout[1]) & 0xFFFFFFFF, float(dropout[0]), _stream(pc)))
+        return out, wts[:col.numel()]
     _check(lib.ncf_attn_forward(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), float(b1), _ptr(rowptr), _ptr(col), _ptr(val),
                                 B, I, _ptr(feat), ldf, Fdim, _ptr(out_bias), _ptr(out), out.stride(0), _ptr(wts), _stream(pc)))
     return out, wts[:col.numel()]
+
+
+def attn_backward(mode: int, pc, pr, w1, rowptr, col, val, feat, wts, dout, dropout: Optional[tuple] = None):
+    """Gradients of attn_forward: (d_pc (B, A), d_pr (I, A), d_w1 (A,) or None, d_feat (I, Fdim)); d b1 is exactly zero."""
+    lib = load_library()
+    _dev(pc, "pc")
+    B, A, ldpc = _rows2d(pc, "pc")
+    I, _, ldpr = _rows2d(pr, "pr")
+    _, Fdim, ldf = _rows2d(feat, "feat")
+    dout = dout.contiguous()
+    d_pc = torch.empty((B, A), dtype=torch.float32, device=pc.device)
+    d_pr = torch.zeros((I, A), dtype=torch.float32, device=pc.device)
+    d_feat = torch.zeros((I, Fdim), dtype=torch.float32, device=pc.device)
+    mlp = mode in (ATT_MLP, ATT_MLP_SCALED)
+    part = torch.empty((B, A), dtype=torch.float32, device=pc.device) if mlp else None
+    scratch = torch.empty(max(col.numel(), 1), dtype=torch.float32, device=pc.device)
+    p, seed = (dropout if dropout is not None else (0.0, 0))
+    _check(lib.ncf_attn_backward(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), _ptr(rowptr), _ptr(col), _ptr(val), B, I, _ptr(feat), ldf, Fdim,
+                                 _ptr(wts), _ptr(dout), dout.stride(0), _ptr(d_pc), A, _ptr(d_pr), A, _ptr(part), _ptr(d_feat), Fdim,
+                                 _ptr(scratch), int(seed) & 0xFFFFFFFF, float(p), _stream(pc)))
+    return d_pc, d_pr, (colsum(part) if mlp and B > 0 else (torch.zeros(A, device=pc.device) if mlp else None)), d_feat
 
 
 def attn_grouped_supported(mode: int, A: int, Fdim: int) -> bool:

@@ -281,7 +281,53 @@ class AttentionNCF(_ScoringMixin, NCF):
         return out
 
     # ------------------------------------------------------------------------------------------ torch training path
+    def _forward_train_hip(self, candidate_items, rated_items, user_matrix, return_attention_weights):
+        """attention_ncf.py:136-224 with autograd recording, on the HIP blocks: the Linear layers (LinearFn), the attention with its
+        softmax and weighted sum (AttnFn: forward and backward kernels; AttentionNet's hidden dropout regenerated from a hash in
+        both), the MLP (mlp_train).  The train-only target masking (:195-205, a candidate must not attend to itself) is decided
+        per rated ENTRY with the reference's own test (isclose of the two embedding rows) and applied by dropping the entry."""
+        from ...autograd import AttnFn, LinearFn, mlp_train
+        li, lu = self.ItemEmbeddings[0], self.UserEmbeddings[0]
+        cand = candidate_items.float().contiguous()
+        rated = rated_items.float().contiguous()
+        cand_emb = LinearFn.apply(cand, li.weight, li.bias, False)
+        rated_emb = LinearFn.apply(rated, li.weight, li.bias, False)
+        ratings = user_matrix if isinstance(user_matrix, SparseRatings) else SparseRatings.from_dense(user_matrix, share_identical_rows=False)
+        if ratings.pair_row is not None:
+            ratings = ratings.expanded()
+        rowptr, col, val = ratings.rowptr, ratings.col, ratings.val
+        if self.training and col.numel():
+            b_of = torch.repeat_interleave(torch.arange(rowptr.numel() - 1, device=col.device), rowptr[1:] - rowptr[:-1])
+            same = torch.isclose(cand_emb.detach()[b_of], rated_emb.detach()[col.long()], atol=1e-5).all(dim=1)
+            col = torch.where(same, torch.full_like(col, -1), col)        # a dropped entry: score -inf, weight 0 (:192-205)
+        dropout = None
+        if self.use_cos_sim_instead:
+            mode, w1, b1 = native.ATT_COS, None, None
+            pc, pr = F.normalize(cand_emb, p=2, dim=1), F.normalize(rated_emb, p=2, dim=1)
+        else:
+            l0, l1 = self.AttentionNet[0], self.AttentionNet[-1]
+            IE = li.out_features
+            pc = LinearFn.apply(cand_emb, l0.weight[:, :IE], l0.bias, False)      # AttentionNet.0 split at the cat boundary (:176)
+            pr = LinearFn.apply(rated_emb, l0.weight[:, IE:], None, False)
+            mode, w1, b1 = native.ATT_MLP, l1.weight.view(-1), l1.bias
+            drop = self.AttentionNet[2]
+            if self.training and isinstance(drop, nn.Dropout) and drop.p > 0:
+                dropout = (float(drop.p), int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))    # host generator: no device sync
+        proj = LinearFn.apply(rated, lu.weight, None, False)        # UserEmbeddings is linear over the weighted sum (:212-216)
+        user_emb, wts = AttnFn.apply(pc, pr, w1, b1, proj, lu.bias, rowptr, col, val, mode, dropout)
+        out = mlp_train(self.MLP, torch.cat((cand_emb, user_emb), dim=1))
+        if return_attention_weights:
+            dense = SparseRatings(rowptr, ratings.col, val, ratings.num_items).to_dense(wts.detach())
+            return out, dense
+        return out
+
     def _forward_train(self, candidate_items, rated_items, user_matrix, return_attention_weights):
+        hip = (candidate_items.is_cuda and not getattr(self, "train_with_torch_ops", False) and not (self.training and self.message_dropout)
+               and (self.use_cos_sim_instead or self.att_dense) and native.attn_grouped_supported(
+                   native.ATT_COS if self.use_cos_sim_instead else native.ATT_MLP,
+                   self.ItemEmbeddings[0].out_features if self.use_cos_sim_instead else int(self.att_dense), self.UserEmbeddings[0].out_features))
+        if hip:
+            return self._forward_train_hip(candidate_items, rated_items, user_matrix, return_attention_weights)
         if isinstance(user_matrix, SparseRatings):
             user_matrix = user_matrix.expanded()
             user_matrix = user_matrix.to_dense(user_matrix.val)

@@ -269,6 +269,35 @@ int ncf_attn_forward(int mode,
                      float* dev_weights,
                      ncf_stream_t stream);
 
+/* Training-step forms of ncf_attn_forward (the reference differentiates attention_ncf.py:176-216 through autograd):
+ *   ncf_attn_forward_dropout  NCF_ATT_MLP with AttentionNet's hidden Dropout(p) active (attention_ncf.py:112-117: one mask element
+ *       per (pair, rated entry, hidden unit), kept values scaled by 1 / (1 - p')): the mask is regenerated in the kernel from a
+ *       counter-based hash of (seed, CSR entry, unit) — NOT torch's Philox stream, same law.  p' = round(p * 65536) / 65536.
+ *   ncf_attn_backward         gradients of ncf_attn_forward[_dropout] given dev_weights (the attention weights the forward wrote)
+ *       and dev_dout (B, Fdim) = d loss / d dev_out_feat:
+ *         dev_d_pc (B, A)            written
+ *         dev_d_pr (I, A)            ADDED to (float atomics): zero it first          dev_d_feat (I, Fdim)  likewise
+ *         dev_d_w1_part (B, A)       per-pair partial rows of d w1 (NCF_ATT_MLP; column-sum them with ncf_colsum)
+ *       d b1 is exactly 0 (a shift of all scores cancels in the softmax); d out_bias = column sums of dev_dout (ncf_colsum).
+ *       dev_scratch: nnz floats.  seed / p as in the forward call (p = 0: no dropout).  NCF_ATT_MLP(_SCALED) and NCF_ATT_COS;
+ *       A, Fdim % 4 == 0 and <= 256. */
+int ncf_attn_forward_dropout(int mode,
+                             const float* dev_pc, int64_t ldpc, const float* dev_pr, int64_t ldpr, int A,
+                             const float* dev_w1, float b1,
+                             const int64_t* dev_rowptr, const int32_t* dev_col, const float* dev_val,
+                             int64_t B, int64_t I,
+                             const float* dev_feat, int64_t ldfeat, int Fdim, const float* dev_out_bias,
+                             float* dev_out_feat, int64_t ldout, float* dev_weights,
+                             uint32_t seed, float p, ncf_stream_t stream);
+int ncf_attn_backward(int mode,
+                      const float* dev_pc, int64_t ldpc, const float* dev_pr, int64_t ldpr, int A, const float* dev_w1,
+                      const int64_t* dev_rowptr, const int32_t* dev_col, const float* dev_val, int64_t B, int64_t I,
+                      const float* dev_feat, int64_t ldfeat, int Fdim,
+                      const float* dev_weights, const float* dev_dout, int64_t lddout,
+                      float* dev_d_pc, int64_t ldd_pc, float* dev_d_pr, int64_t ldd_pr, float* dev_d_w1_part,
+                      float* dev_d_feat, int64_t ldd_feat, float* dev_scratch,
+                      uint32_t seed, float p, ncf_stream_t stream);
+
 /* The same computation for batches in which several pairs share one rated set (evaluation batches grouped by user;
  * serving one user against the whole catalogue, reference webapp/backend.py:78-121), LDS-tiled: the CSR has one row
  * per USER (n_rows rows), the B pairs are listed user by user —

@@ -10,9 +10,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _grads_close(gpu_model, cpu_model, rtol=2e-5):
+def _grads_close(gpu_model, cpu_model, rtol=2e-5, exactly_zero=()):
     for (n, p), (_, q) in zip(gpu_model.named_parameters(), cpu_model.named_parameters()):
         assert p.grad is not None, n
+        if n in exactly_zero:      # a gradient that is 0 by construction: the kernels return 0, CPU autograd its rounding noise
+            assert float(p.grad.abs().max()) == 0.0 and float(q.grad.abs().max()) < 1e-5, n
+            continue
         a, b = p.grad.cpu().double(), q.grad.double()
         scale = float(b.abs().max()) + 1e-30
         err = float((a - b).abs().max())
@@ -486,3 +489,119 @@ def test_graph_ncf_trains_with_message_dropout_on_hip_blocks(gpu):
     with torch.no_grad():
         s1 = m(graph, users[:64], items[:64], gpu)
     assert torch.isfinite(s1).all()
+
+
+# ----------------------------------------------------------------------------- AttentionNCF training step on the HIP blocks
+def _attention_batch(B, I, Fdim, seed):
+    g = torch.Generator().manual_seed(seed)
+    rated = (torch.rand(I, Fdim, generator=g) < 0.3).float() * torch.rand(I, Fdim, generator=g)
+    cand = (torch.rand(B, Fdim, generator=g) < 0.3).float() * torch.rand(B, Fdim, generator=g)
+    cand[1] = rated[3]                                   # a candidate that is one of the rated items: masked while training
+    um = torch.where(torch.rand(B, I, generator=g) < 0.5, torch.randint(1, 11, (B, I), generator=g).float() * 0.5 - 2.9, torch.zeros(B, I))
+    um[1, 3] = 1.5                                       # ... and the user did rate it
+    um[2] = 0                                            # a user without rated items: softmax NaN -> 0 row
+    y = torch.rand(B, 1, generator=g) * 5
+    return cand, rated, um, y
+
+
+@pytest.mark.parametrize("cosine,att_dense", [(False, 32), (True, None), (False, 128)])
+@pytest.mark.parametrize("training", [True, False])
+def test_attention_ncf_training_step_gradients(gpu, cosine, att_dense, training):
+    """AttentionNCF training step (attention_ncf.py:136-224 under autograd) on the HIP blocks — Linear layers, the attention
+    kernel and ITS BACKWARD kernel (softmax, rating-weighted sum, AttentionNet), MLP — against the same model with torch ops
+    on the CPU: loss, attention weights and every parameter gradient; with the train-only self-attention mask, an all-unrated
+    user and dropout off (masks are RNG-dependent; the fused hidden dropout has its own test)."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
+    B, I, Fdim = 48, 40, 36
+    cand, rated, um, y = _attention_batch(B, I, Fdim, seed=21)
+    torch.manual_seed(4)
+    m_cpu = AttentionNCF(item_dim=Fdim, item_emb=64, user_emb=64, att_dense=att_dense, mlp_dense_layers=[128],
+                         use_cos_sim_instead=cosine, dropout_rate=0.0)
+    m_cpu.train(training)
+    m_gpu = copy.deepcopy(m_cpu).to(gpu)
+    m_gpu.train(training)
+    out_c, w_c = m_cpu(cand, rated, um, return_attention_weights=True)
+    loss_c = torch.nn.functional.mse_loss(out_c, y, reduction="sum")
+    loss_c.backward()
+    out_g, w_g = m_gpu(cand.to(gpu), rated.to(gpu), um.to(gpu), return_attention_weights=True)
+    assert out_g.requires_grad
+    loss_g = torch.nn.functional.mse_loss(out_g, y.to(gpu), reduction="sum")
+    loss_g.backward()
+    assert abs(float(loss_g.detach()) - float(loss_c.detach())) <= 2e-5 * abs(float(loss_c.detach()))
+    assert float((w_g.cpu() - w_c).abs().max()) <= 1e-5
+    if training:
+        assert float(w_c[1, 3]) == 0.0 and float(w_g[1, 3]) == 0.0      # the candidate's own rated entry is masked
+    assert float(w_g[2].abs().sum()) == 0.0
+    # AttentionNet's output bias shifts every score of a row alike: it cancels in the softmax, its gradient is exactly zero
+    _grads_close(m_gpu, m_cpu, rtol=1e-4, exactly_zero=("AttentionNet.3.bias",))
+
+
+def test_attention_hidden_dropout_forward_and_backward_agree(gpu):
+    """AttentionNet's hidden dropout on the HIP kernels (ncf_attn_forward_dropout / ncf_attn_backward with the same seed): the
+    backward is the gradient of THAT forward — central differences through the seeded kernel on a handful of pc / pr / w1
+    elements — a different seed gives different attention weights, p = 0 equals the plain kernel bit for bit."""
+    from deeprecommendation_amd import native
+    g = torch.Generator().manual_seed(3)
+    B, I, A, Fd, nnz = 6, 50, 32, 16, 20
+    pc = (torch.randn(B, A, generator=g) * 0.5).double()
+    pr = (torch.randn(I, A, generator=g) * 0.5).double()
+    w1 = torch.randn(A, generator=g).double()
+    feat = torch.randn(I, Fd, generator=g).to(gpu)
+    col = torch.stack([torch.randperm(I, generator=g)[:nnz].sort().values for _ in range(B)]).reshape(-1).to(torch.int32).to(gpu)
+    val = (torch.randint(1, 11, (B * nnz,), generator=g).float() * 0.5 - 2.9).to(gpu)
+    rowptr = torch.arange(0, (B + 1) * nnz, nnz, dtype=torch.int64, device=gpu)
+    gout = torch.randn(B, Fd, generator=g).to(gpu)
+    drop = (0.3, 4242)
+
+    def loss(pc_, pr_, w1_, d=drop):
+        out, wts = native.attn_forward(native.ATT_MLP, pc_.float().to(gpu).contiguous(), pr_.float().to(gpu).contiguous(),
+                                       w1_.float().to(gpu).contiguous(), 0.2, rowptr, col, val, feat, dropout=d)
+        return float((out.double() * gout.double()).sum()), wts
+
+    l0, wts = loss(pc, pr, w1)
+    d_pc, d_pr, d_w1, d_feat = native.attn_backward(native.ATT_MLP, pc.float().to(gpu), pr.float().to(gpu), w1.float().to(gpu), rowptr, col, val,
+                                                    feat, wts, gout, dropout=drop)
+    eps = 1e-2
+    for (name, t, grad, idx) in (("pc", pc, d_pc, (2, 5)), ("pc", pc, d_pc, (4, 31)), ("pr", pr, d_pr, (int(col[3]), 7)),
+                                 ("pr", pr, d_pr, (int(col[45]), 0)), ("w1", w1, d_w1, (9,)), ("w1", w1, d_w1, (30,))):
+        tp, tm = t.clone(), t.clone()
+        tp[idx] += eps
+        tm[idx] -= eps
+        args = {"pc": (tp, pr, w1), "pr": (pc, tp, w1), "w1": (pc, pr, tp)}[name], {"pc": (tm, pr, w1), "pr": (pc, tm, w1), "w1": (pc, pr, tm)}[name]
+        num = (loss(*args[0])[0] - loss(*args[1])[0]) / (2 * eps)
+        ana = float(grad[idx])
+        assert abs(num - ana) <= 3e-2 * max(abs(num), abs(ana)) + 2e-3, (name, idx, num, ana)
+    _, wts_other = loss(pc, pr, w1, (0.3, 7))
+    assert not torch.equal(wts, wts_other)
+    out_p0, w_p0 = native.attn_forward(native.ATT_MLP, pc.float().to(gpu), pr.float().to(gpu), w1.float().to(gpu), 0.2, rowptr, col, val, feat, dropout=(0.0, 1))
+    out_pl, w_pl = native.attn_forward(native.ATT_MLP, pc.float().to(gpu), pr.float().to(gpu), w1.float().to(gpu), 0.2, rowptr, col, val, feat)
+    assert torch.equal(out_p0, out_pl) and torch.equal(w_p0, w_pl)
+
+
+def test_attention_ncf_trains_with_default_dropout_on_hip_blocks(gpu):
+    """Default hyper-parameters (dropout_rate 0.2: AttentionNet's hidden dropout and the MLP's) on the HIP blocks + FusedAdam:
+    the loss goes down and the eval-mode HIP scoring (grouped kernel, scaled operands) follows the trained weights."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
+    from deeprecommendation_amd.optim import FusedAdam
+    from oracle import ncf_oracle as O
+    from test_gpu_basic import assert_close
+    B, I, Fdim = 256, 60, 48
+    cand, rated, um, _ = _attention_batch(B, I, Fdim, seed=5)
+    y = (cand[:, :4].sum(1, keepdim=True) + 1.0)
+    torch.manual_seed(1)
+    m = AttentionNCF(item_dim=Fdim, item_emb=64, user_emb=64, att_dense=64, mlp_dense_layers=[128]).to(gpu).train()
+    opt = FusedAdam(m.parameters(), lr=3e-3)
+    c, r, u, yy = cand.to(gpu), rated.to(gpu), um.to(gpu), y.to(gpu)
+    losses = []
+    for step in range(40):
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(m(c, r, u), yy)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.6 * losses[0], losses[::8]
+    m.eval()
+    with torch.no_grad():
+        out = m(c, r, u)
+    state = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    assert_close(out, O.attention_ncf_forward(state, cand, rated, um))
