@@ -135,8 +135,8 @@ class RowShardedTable:
     CAP_SLACK = 1.25      # capacity = largest bucket seen at negotiation x slack, rounded up to CAP_ROUND ids
     CAP_ROUND = 256
 
-    def __init__(self, local_rows: torch.Tensor, total_rows: int, group=None, local_ops=None):
-        self.comm = Comm(group)
+    def __init__(self, local_rows: torch.Tensor, total_rows: int, group=None, local_ops=None, comm=None):
+        self.comm = comm if comm is not None else Comm(group)   # `comm`: an object with Comm's interface (tests: a loopback)
         self.group = group
         self.world, self.rank = self.comm.world, self.comm.rank
         self.total_rows = int(total_rows)
@@ -267,15 +267,15 @@ class ShardedBasicNCF:
 
     def __init__(self, user_table, num_users, item_table, num_items, mlp_weights: Sequence[torch.Tensor],
                  mlp_biases: Sequence[Optional[torch.Tensor]], replicate_items=False, group=None, local_ops=None,
-                 dtype=None, exchange="bounded", depth=2):
+                 dtype=None, exchange="bounded", depth=2, comm=None):
         if exchange not in ("bounded", "unique"):
             raise ValueError("exchange must be 'bounded' or 'unique'")
         self.ops = local_ops or _HipOps
         self.exchange = exchange
-        self.users = RowShardedTable(user_table, num_users, group, local_ops)
+        self.users = RowShardedTable(user_table, num_users, group, local_ops, comm)
         self.replicate_items = replicate_items
         self.items_full = item_table.contiguous() if replicate_items else None
-        self.items = None if replicate_items else RowShardedTable(item_table, num_items, group, local_ops)
+        self.items = None if replicate_items else RowShardedTable(item_table, num_items, group, local_ops, comm)
         self.weights = [w.detach().float().contiguous() for w in mlp_weights]
         self.biases = [None if b is None else b.detach().float().contiguous() for b in mlp_biases]
         self.packed = None

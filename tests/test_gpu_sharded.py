@@ -180,3 +180,56 @@ def test_partitioned_lightgcn_two_ranks_one_gpu(gpu, mode):
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_two_rank_graph_worker, args=(2, os.path.join(d, "store"), mode), nprocs=2, join=True)
+
+
+class _LoopbackComm:
+    """Stand-in for sharded.Comm that moves bytes on the device only (this rank plays every peer): the results are not a real
+    exchange, the ORDER OF OPERATIONS on the streams is — what the no-host-synchronisation test needs."""
+
+    def __init__(self, world, rank):
+        self.world, self.rank, self.on, self.backend, self.group = world, rank, True, "loopback", None
+
+    def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        assert out_splits is None and in_splits is None        # the bounded exchange never needs sizes
+        out.view(self.world, -1).copy_(inp.view(self.world, -1)[self.rank].unsqueeze(0).expand(self.world, -1))
+        return out
+
+    def all_reduce(self, t, op=None):
+        return t
+
+
+def test_bounded_exchange_has_no_host_synchronisation(gpu):
+    """SURVEY §8e / VERDICT item 5: once the capacity is agreed, a pipelined step of the row-sharded scoring path (device-side owner
+    bucketing, equal-split exchanges on the second stream, fused scoring on the first) must not synchronise the host at all.
+    torch's sync debug mode raises on ANY synchronising call (.item(), .tolist(), .cpu(), nonzero, ...)."""
+    from deeprecommendation_amd.sharded import RowShardedTable, ShardedBasicNCF
+    world, rank = 4, 1
+    g = torch.Generator().manual_seed(0)
+    U, I, E, B = 40_000, 5_000, 128, 8192
+    ulo, uhi = RowShardedTable.shard_bounds(U, world, rank)
+    tu = (torch.randn(uhi - ulo, E, generator=g) * 0.05).to(torch.bfloat16).to(gpu)
+    ti = (torch.randn(I, E, generator=g) * 0.05).to(torch.bfloat16).to(gpu)
+    dims = [2 * E, 256, 128, 1]
+    ws = [(torch.randn(dims[k + 1], dims[k], generator=g) / dims[k] ** 0.5).to(gpu) for k in range(3)]
+    bs = [(torch.randn(dims[k + 1], generator=g) * 0.1).to(gpu) for k in range(3)]
+    model = ShardedBasicNCF(tu, U, ti, I, ws, bs, replicate_items=True, dtype=torch.bfloat16, exchange="bounded", comm=_LoopbackComm(world, rank))
+    assert model._xstream is not None
+    ups = [torch.randint(0, U, (B,), generator=g).to(gpu) for _ in range(6)]
+    ips = [torch.randint(0, I, (B,), generator=g).to(gpu) for _ in range(6)]
+    model.negotiate_capacity(ups[0], ips[0])               # the one host read
+    model(ups[0], ips[0])                                  # buffers allocated
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        t = model.submit(ups[0], ips[0])
+        outs = []
+        for k in range(6):
+            nxt = model.submit(ups[(k + 1) % 6], ips[(k + 1) % 6])
+            outs.append(model.score(t))
+            t = nxt
+        model.score(t)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(o).all() for o in outs)
+    model.check()                                          # (this one synchronises: end of the pass)
