@@ -31,7 +31,7 @@ static const struct {
     const char* name;
     int id, lo, hi;
 } kOptions[] = {
-    {"bf16_kernel", NCF_OPT_BF16_KERNEL, 0, 2},
+    {"bf16_kernel", NCF_OPT_BF16_KERNEL, 0, 3},
     {"linear_kernel", NCF_OPT_LINEAR_KERNEL, 0, 2},
     {"linear_kslices", NCF_OPT_LINEAR_KSLICES, 0, 8},
     {"attn_grouped_kernel", NCF_OPT_ATTN_GROUPED_KERNEL, 0, 2},

@@ -10,13 +10,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["abi.hip", "gather.hip", "mlp_fused.hip", "linear.hip", "spmm.hip", "attn.hip", "mlp_bf16.hip", "backward.hip", "exchange.hip"]
+SOURCES = ["abi.hip", "gather.hip", "mlp_fused.hip", "linear.hip", "spmm.hip", "attn.hip", "mlp_bf16.hip", "mlp_bf16_ws8.hip", "backward.hip", "exchange.hip"]
 LIB = os.path.join(PKG, "libncf_hip.so")
 ARCH = "gfx950"
 # per-file flags.  mlp_bf16.hip: MFMA accumulators in VGPRs instead of AGPRs (the ReLU / bf16 conversion of the hidden
 # layers reads them with VALU instructions; in AGPR form hipcc copies whole 16-register tuples first) — measured with
 # tools/ab_bf16.py, bit-identical results: weight-stationary kernel 222 -> 216 us (1 M pairs), streaming kernel 20.4 -> 19.9 us
-EXTRA_FLAGS = {"mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "mlp_bf16_ws8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -34,7 +34,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(HERE, "ncf_common.h"), os.path.join(PKG, "..", "include", "ncf_abi.h")]
+    deps = sources() + [os.path.join(HERE, "ncf_common.h"), os.path.join(HERE, "mlp_bf16.h"), os.path.join(PKG, "..", "include", "ncf_abi.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

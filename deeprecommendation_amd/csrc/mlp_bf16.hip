@@ -13,7 +13,7 @@
 // barrier per slab; A fragments are lane-linear in LDS (conflict-free ds_read_b128).
 // Bound at config 5 (E = 128): bf16 MFMA 196 864 FLOP/pair (2.5 PF -> 12.7 G pairs/s) vs HBM 532 B/pair
 // (8 TB/s -> 15 G pairs/s): roughly balanced.
-#include "ncf_common.h"
+#include "mlp_bf16.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -25,9 +25,6 @@
 #endif
 #ifndef NCF_BF16_WGW
 #define NCF_BF16_WGW 8       // waves per workgroup sharing a weight slab; measured: 8 -> 19.6 us, 4 (two WGs per CU) -> 20.4, 2 -> 24-28
-#endif
-#ifndef NCF_BF16_STAMP
-#define NCF_BF16_STAMP 0     // diagnostic builds only (tools/ab_bf16.py): phase stamps written behind the outputs
 #endif
 #ifndef NCF_BF16_ABLATE
 #define NCF_BF16_ABLATE 0    // diagnostics: 1 = no gathered-row loads, 2 = no weight slab copies / barriers, 3 = rows from a 1 MiB window,
@@ -42,61 +39,6 @@ static unsigned long long* g_bf16_dbg = nullptr;
 #else
 #define BF16_STAMP(i) do { } while (0)
 #endif
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-struct Bf16Args {
-    const unsigned short* tabA; int64_t rowsA; int64_t ldA;
-    const unsigned short* tabB; int64_t rowsB; int64_t ldB;
-    const int64_t* idxA; const int64_t* idxB;
-    int64_t B; int EA;
-    const unsigned short* Wp1; const float* b1;
-    const unsigned short* Wp2; const float* b2;
-    const float* wl; const float* bl;
-    float* out; int32_t* oob;
-#if NCF_BF16_STAMP
-    unsigned long long* dbg;
-#endif
-};
-
-__device__ __forceinline__ u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
-
-__device__ __forceinline__ bf16x8_t as_bf16x8(u32x4 v) {
-    union { u32x4 u; bf16x8_t b; } c;
-    c.u = v;
-    return c.b;
-}
-
-// relu + round-to-nearest-even to bf16 of 8 accumulator registers -> one MFMA B fragment
-__device__ __forceinline__ bf16x8_t pack_relu8(const f32x16& acc, int base) {
-    bf16x8_t r;
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        f32x2 v = {fmaxf(acc[base + j], 0.f), fmaxf(acc[base + j + 1], 0.f)};
-        bf16x2_t p = __builtin_convertvector(v, bf16x2_t);
-        r[j] = p[0];
-        r[j + 1] = p[1];
-    }
-    return r;
-}
-
-// the same fragment with the ReLU applied AFTER the rounding, on the packed pairs as signed 16-bit integers (a negative
-// bf16 is a negative int16; rounding keeps the sign, so the result is bit-identical): 4 cvt + 4 v_pk_max_i16
-// instead of 16 v_max_f32 + 4 cvt — this matters where the conversion has to hide in MFMA issue gaps
-typedef short s16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bf16x8_t pack_relu8_int(const f32x16& acc, int base) {
-    union { bf16x8_t b; s16x2_t s[4]; } r;
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        f32x2 v = {acc[base + j], acc[base + j + 1]};
-        union { bf16x2_t b; s16x2_t s; } p;
-        p.b = __builtin_convertvector(v, bf16x2_t);
-        r.s[j >> 1] = __builtin_elementwise_max(p.s, (s16x2_t){0, 0});
-    }
-    return r.b;
-}
 
 template <int K0, int N1, int N2>
 __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(Bf16Args a) {
@@ -351,23 +293,6 @@ __global__ __launch_bounds__(NCF_BF16_WGW * 64, 2) void score_fused_bf16_kernel(
 #define WS_STAMP(k) do { } while (0)
 #endif
 
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// LDS-DMA by inline asm: the compiler's waitcnt pass treats the builtin form as an out-of-order LGKM event and turns
-// every later `s_waitcnt lgkmcnt(N)` of the kernel into lgkmcnt(0) (measured: ~100 stall cycles per k-step at one wave
-// per SIMD); hidden in asm, its own LDS reads keep their counted waits and the DMAs are counted by hand (vmcnt).
-// M0 (the wave-uniform LDS destination) is saved and restored inside the statement.
-__device__ __forceinline__ void dma16(const void* g, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ void dma4(const void* g, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
-}
-
 template <int K0, int N1, int N2>
 struct WsLayout {
     static constexpr int P = 64, CTN = 2;                 // pairs per tile, 32-pair column tiles per tile
@@ -391,7 +316,6 @@ struct WsLayout {
 #define SGB_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
 #define SGB_DSW(n) __builtin_amdgcn_sched_group_barrier(0x200, n, 0)
 
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }  // one v_med3_f32
 
 template <int K0, int N1, int N2>
 __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const int64_t* __restrict__ idxA,
@@ -906,9 +830,13 @@ int bf16_score(const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, i
     // 256-pair workgroups go to a second round past one per CU); 131 072: 33.8 vs 38.9; 4 M: 833-885 vs 1044-1066.
     // ncf_set_option("bf16_kernel", 1 = ws | 2 = stream) overrides the choice (tests run every batch size through both).
     bool ws = NCF_BF16_WS && B >= NCF_BF16_WS_MIN_PAIRS;
-    if (const int force = option(NCF_OPT_BF16_KERNEL)) ws = force == 1;
+    if (const int force = option(NCF_OPT_BF16_KERNEL)) ws = force == 1 || force == 3;
     ws = ws && EA % 64 == 0 && EB % 64 == 0 && idxA && (EB == 0 || idxB);
     if (ws && !idxB) a.idxB = idxA;   // single table: the id DMA's table-B lanes fetch valid (unused) words
+    if (ws && B < (int64_t(1) << 31) - 64 && option(NCF_OPT_BF16_KERNEL) == 3 && ws8_shape_ok(dims[0], dims[1], n_layers == 3 ? dims[2] : 0)) {
+        launch_ws8_bf16(dims[0], a, (const unsigned char*)(P + L.zeros), s);
+        return check_launch("ncf_score_fused(bf16)");
+    }
     bf16_dispatch(dims[0], dims[1], n_layers == 3 ? dims[2] : 0, &a, (const unsigned char*)(P + L.zeros), ws, s);
     return check_launch("ncf_score_fused(bf16)");
 }

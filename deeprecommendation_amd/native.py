@@ -113,7 +113,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
 
 # ncf_set_option values by name (include/ncf_abi.h); 0 / "auto" = choose by shape
 OPTION_VALUES = {
-    "bf16_kernel": {"auto": 0, "ws": 1, "stream": 2},
+    "bf16_kernel": {"auto": 0, "ws": 1, "stream": 2, "ws8": 3},
     "linear_kernel": {"auto": 0, "rs": 1, "rsp": 2},
     "linear_kslices": {"auto": 0, "4": 4, "8": 8},
     "attn_grouped_kernel": {"auto": 0, "lds": 1, "scalar": 2},

@@ -277,19 +277,20 @@ def test_full_size_cfg5_properties(native, gpu, kernel_option):
         iu[0], iu[1], ii[0], ii[1] = 0, U - 1, I - 1, 0
         perm = torch.randperm(B, device=gpu, generator=g)
         outs = {}
-        for kernel in ("stream", "ws"):
+        for kernel in ("stream", "ws", "ws8"):
             kernel_option("bf16_kernel", kernel)
             out = native.score_fused(tu, iu, ti, ii, packed)
             outp = native.score_fused(tu, iu[perm].contiguous(), ti, ii[perm].contiguous(), packed)
             assert torch.equal(outp, out[perm]), kernel
             outs[kernel] = out
         assert_close(outs["ws"], outs["stream"].cpu(), rtol=2e-3)
+        assert_close(outs["ws8"], outs["stream"].cpu(), rtol=2e-3)
         sub = torch.cat((torch.arange(0, 4, device=gpu), torch.arange(4, B, 1021, device=gpu)))
         x = torch.cat((tu[iu[sub]], ti[ii[sub]]), 1).double().cpu()
         h = torch.relu(x @ wr[0].t() + bs[0].double().cpu()).float().to(torch.bfloat16).double()
         h = torch.relu(h @ wr[1].t() + bs[1].double().cpu())
         ref = (h @ wr[2].t() + bs[2].double().cpu()).float()
-        for kernel in ("stream", "ws"):
+        for kernel in ("stream", "ws", "ws8"):
             assert_close(outs[kernel][sub], ref, rtol=2e-3)
     native.check_oob(gpu)
     del tu, ti
@@ -299,7 +300,7 @@ def test_full_size_cfg5_properties(native, gpu, kernel_option):
 # ----------------------------------------------------------------------------- bf16 fused path (BASELINE config 5 arithmetic)
 @pytest.mark.parametrize("E,hidden", [(128, [256, 128]), (128, [256]), (64, [256, 128]), (64, [256])])
 @pytest.mark.parametrize("B", [1, 63, 255, 256, 257, 3000, 40000, 100001, 140000])
-@pytest.mark.parametrize("kernel", ["stream", "ws", "auto"])
+@pytest.mark.parametrize("kernel", ["stream", "ws", "ws8", "auto"])
 def test_score_fused_bf16_vs_oracle(gpu, kernel_option, E, hidden, B, kernel):
     """bf16 tables / weights, fp32 accumulate: gathers are bit-exact on the bf16 table; the MLP is compared with the
     oracle evaluated on the same bf16-rounded operands — tolerance 2e-3 relative (builder-defined: BASELINE pins only
@@ -334,7 +335,7 @@ def test_score_fused_bf16_vs_oracle(gpu, kernel_option, E, hidden, B, kernel):
     assert torch.equal(native.gather_concat(tu, u.to(gpu)), tu[u.to(gpu)])
 
 
-@pytest.mark.parametrize("kernel", ["stream", "ws"])
+@pytest.mark.parametrize("kernel", ["stream", "ws", "ws8"])
 def test_score_fused_bf16_exact_small_integers(native, gpu, kernel_option, kernel):
     """Exact check of the packed layer-2 k permutation: small integer data is exact in bf16 x bf16 -> fp32."""
     kernel_option("bf16_kernel", kernel)
@@ -356,7 +357,7 @@ def test_score_fused_bf16_exact_small_integers(native, gpu, kernel_option, kerne
     assert torch.equal(out.cpu().double(), ref)
 
 
-@pytest.mark.parametrize("kernel", ["stream", "ws"])
+@pytest.mark.parametrize("kernel", ["stream", "ws", "ws8"])
 def test_score_fused_out_of_range_rows_read_as_zeros(native, gpu, kernel_option, kernel):
     """ABI contract: an out-of-range id never faults; that table's part of the row is zeros and the sticky flag is set."""
     kernel_option("bf16_kernel", kernel)

@@ -1,12 +1,12 @@
 #!/bin/bash
-# build a variant library: ab_build.sh <name> <file.hip> <flags...>; result deeprecommendation_amd/libncf_hip_<name>.so
+# build a variant library: ab_build.sh <name> <file.hip[,file2.hip...]> <flags...>; result deeprecommendation_amd/libncf_hip_<name>.so
 set -e
-NAME=$1; SRC=$2; shift 2
+NAME=$1; SRCS=",$2,"; shift 2
 cd /root/repo/deeprecommendation_amd/csrc
 mkdir -p build/$NAME
-for f in abi gather mlp_fused linear spmm attn mlp_bf16 backward exchange; do
-  if [ "$f.hip" == "$SRC" ]; then
-    EXTRA=""; [ "$f" == "mlp_bf16" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
+for f in abi gather mlp_fused linear spmm attn mlp_bf16 mlp_bf16_ws8 backward exchange; do
+  if [[ "$SRCS" == *",$f.hip,"* ]]; then
+    EXTRA=""; [[ "$f" == mlp_bf16* ]] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $EXTRA "$@" -c $f.hip -o build/$NAME/$f.hip.o
     OBJS="$OBJS build/$NAME/$f.hip.o"
   else
