@@ -823,17 +823,20 @@ int bf16_score(const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, i
 #if NCF_BF16_STAMP
     a.dbg = g_bf16_dbg;
 #endif
-    // Weight-stationary persistent kernel whenever the row widths are whole 128-byte units and ids are given, else the
-    // slab-streaming one.  Measured (tools/ab_bf16.py, E = 128, 256-256-128-1, interleaved in one process), ws vs streaming:
-    // 512..8192 pairs 7.6-8.0 vs 13.6-14.6 us; 16 384: 8.7 vs 15.0; 32 768: 13.3 vs 16.8; 49 152: 16.6 vs 18.4; 65 536: 20.3 vs
-    // 19.9 (4 M-row tables) and 20.9 vs 23.0 (100 M-row tables, config 5); 73 728: 21.9 vs 34.2 (the streaming kernel's
-    // 256-pair workgroups go to a second round past one per CU); 131 072: 33.8 vs 38.9; 4 M: 833-885 vs 1044-1066.
-    // ncf_set_option("bf16_kernel", 1 = ws | 2 = stream) overrides the choice (tests run every batch size through both).
+    // Kernel choice (ncf_set_option("bf16_kernel", 1 = ws | 2 = stream | 3 = ws8) overrides it; tests run every batch size through all):
+    //   * ws8, the 8-wave weight-stationary kernel (mlp_bf16_ws8.hip), for the NCF shape it is built for: two tables of equal width
+    //     (EA = EB = K0/2 in {64, 128}), MLP K0-256-128-1, ids given.  tools/ab_bf16_opt.py (E = 128, 4 M + 1 M rows), ws8 vs ws vs
+    //     stream: 16 384 pairs 10.1 / 10.9 / 14.4 us, 32 768: 11.9 / 12.8 / 15.0, 65 536: 16.9 / 18.3 / 18.0, 131 072: 28.3 / 30.2 / 34.4,
+    //     262 144: 51.7 / 54.9 / 71.8, 1 M: 185 / 213-222 / 288, 4 M: 716-740 / 821-870 / 1 115; below 16 384 pairs all are launch-bound;
+    //   * ws, the 4-wave weight-stationary kernel, whenever the row widths are whole 128-byte units and ids are given;
+    //   * the slab-streaming kernel otherwise.
+    const int force = option(NCF_OPT_BF16_KERNEL);
     bool ws = NCF_BF16_WS && B >= NCF_BF16_WS_MIN_PAIRS;
-    if (const int force = option(NCF_OPT_BF16_KERNEL)) ws = force == 1 || force == 3;
+    if (force) ws = force == 1 || force == 3;
     ws = ws && EA % 64 == 0 && EB % 64 == 0 && idxA && (EB == 0 || idxB);
     if (ws && !idxB) a.idxB = idxA;   // single table: the id DMA's table-B lanes fetch valid (unused) words
-    if (ws && B < (int64_t(1) << 31) - 64 && option(NCF_OPT_BF16_KERNEL) == 3 && ws8_shape_ok(dims[0], dims[1], n_layers == 3 ? dims[2] : 0)) {
+    const int N2 = n_layers == 3 ? dims[2] : 0;
+    if (ws && force != 1 && EA == EB && B < (int64_t(1) << 31) - 64 && ws8_shape_ok(dims[0], dims[1], N2)) {
         launch_ws8_bf16(dims[0], a, (const unsigned char*)(P + L.zeros), s);
         return check_launch("ncf_score_fused(bf16)");
     }

@@ -2,33 +2,55 @@
 //
 // Why a second weight-stationary form: the 4-wave kernel of mlp_bf16.hip keeps ONE wave per SIMD (the weights fill its
 // registers), and a lone wave issues one instruction per ~4-5 cycles — its ~800 instructions per 64-pair tile cost as much
-// as the tile's 96 MFMAs (3 072 cycles) before any stall.  Here a 512-thread workgroup puts TWO waves on every SIMD, so one
-// wave's VALU / LDS / DMA / scalar work issues under its partner's MFMAs.  The price is 256 registers per wave, which
-// forces an 8-way split of the weights:
-//   * layer 1: wave w keeps neurons [32w, 32w+32) (Q1 A fragments = 64 registers at K0 = 256) and runs them over BOTH
-//     32-pair column tiles of the 64-pair tile: 2 x Q1 MFMAs (v_mfma_f32_32x32x16_bf16);
-//   * layer 2: wave w keeps neurons [32(w&3), +32) (16 A fragments = 64 registers; the two waves of a SIMD hold the same
-//     slice) and runs them over ONE column tile, ct = w >> 2: 16 MFMAs.
-// 48 MFMAs per wave and tile = 96 per SIMD, the same matrix work as before.  What crosses LDS is unchanged (the X image
-// filled by LDS-DMA in 8-pair x 128-byte pieces, three tiles deep; H1 as ready-made layer-2 B fragments; the formats are
-// the 4-wave kernel's, so W1 / W2 keep their packing), but every wave now reads all of X and half of H1: 384 KB of
-// ds_read_b128 per tile and CU = 1 536 LDS cycles of the 3 072.
+// as the tile's 96 MFMAs (3 072 cycles) before any stall.  Here a 512-thread workgroup puts TWO waves on every SIMD and
+// splits the ROLES between them, so that neither needs more than 256 registers:
+//   * "A" waves 0-3 own layer 1: wave a keeps neurons [64a, 64a+64) (2 x Q1 A fragments = 128 registers at K0 = 256) and does
+//     nothing but read X fragments, issue MFMAs and turn finished accumulators into H1 (ReLU, bf16, ready-made layer-2 B
+//     fragments).  No vector-memory instruction: an A wave never stalls behind an LDS-DMA.
+//   * "B" waves 4-7 own layer 2 and all I/O: wave 4+b keeps neurons [32b, 32b+32) of layer 2 (16 A fragments), runs them over
+//     H1, does the last layer's dot on its accumulators, and issues every LDS-DMA (ids, gathered rows).  It needs a third of
+//     the SIMD's matrix pipe, so the ~100-200 cycles an LDS-DMA of random rows holds its wave are affordable there.
+// The unit of work is 32 pairs (one MFMA column tile).  Per SIMD and unit: 32 (A) + 16 (B) MFMAs = 1 536 matrix-pipe cycles;
+// per CU and unit 4 x 16 KB (X, each fragment feeds two MFMAs) + 4 x 16 KB (H1) of ds_read_b128 = 512 LDS cycles — the 4-wave
+// kernel's traffic, a third less than an 8-way split of both layers.  The H1 format and the W1 / W2 packing are the 4-wave
+// kernel's; inside an X piece the chunks are stored pair-major with an XOR swizzle (see below).
 //
-// Schedule.  "Team 0" = waves 0-3, "team 1" = waves 4-7 (SIMD partners: w and w+4).  Team 1 runs layer 1 of column tile 0
-// one tile ahead, so that both teams carry the same MFMA count between the two barriers of a tile and H1 needs one buffer:
-//     S1(t):  team 0:  L1(t) ct0  | dot(t-1) ct0 -> red      team 1:  L2(t-1) ct1 | pack ct0(t) -> H1
-//                      L1(t) ct1  | pack ct0(t) -> H1                 L1(t) ct1   | dot(t-1) ct1 -> red
-//     -- wait rows(t+1) -- barrier alpha(t): H1(ct0)(t), red(t-1), X(t+1) visible; X(t) is free --
-//     S2(t):  team 0:  L2(t) ct0  | pack ct1(t) -> H1        team 1:  L1(t+1) ct0 | pack ct1(t) -> H1
-//                      both: out(t-1) (wave 0), row pointers(t+3), ids DMA(t+4), row DMAs(t+3) into X(t)'s buffer
-//     -- barrier beta(t): H1(ct1)(t) visible --
-// Vector-memory queue of a wave, oldest first: ... rows(t+1) | [out] ids(t+3) rows(t+2) | [out] ids(t+4) rows(t+3): at
-// alpha(t) `s_waitcnt vmcnt(NCU)` leaves only rows(t+2) in flight.  DMAs are issued only for tiles that exist.
+// Pipeline, one barrier per phase (phase k = unit k of this workgroup; unit j's stages):
+//     phase j    A: layer 1 of unit j (X slot j % NU)            | pack(j-1) -> H1[(j-1)&1]; out(j-4) (wave 0)
+//     phase j+1  A: pack(j) -> H1[j&1]
+//     phase j+2  B: layer 2 of unit j from H1[j&1] -> acc2[j&1]
+//     phase j+3  B: last-layer dot of unit j -> red[j&1]
+//     phase j+4  A (wave 0): out(j) = sum of red[j&1] + bias
+// and B, in phase k: row pointers of unit k+D from the ids that arrived D phases ago, ids DMA of unit k+2D, row DMAs of unit
+// k+D into slot (k+D) % NU (D < NU: that slot's unit was consumed before phase k); before the barrier it waits until only
+// the DMAs of the last D-2 phases are in flight, i.e. rows(k+2) have landed: A prefetches the first fragments of unit k+1 before
+// the barrier of phase k and never waits for LDS after a barrier.
 #include "mlp_bf16.h"
 #include <type_traits>
 
+#ifndef NCF_WS8_ABLATE
+#define NCF_WS8_ABLATE 0      // diagnostics: 1 = no row DMAs, 2 / 3 = rows from a 1 MiB / 64 MiB window of table A
+#endif
+#ifndef NCF_WS8_PRIO
+#define NCF_WS8_PRIO 0        // 1 = B waves at s_setprio 1, 2 = A waves at s_setprio 1
+#endif
 #ifndef NCF_WS8_RING
 #define NCF_WS8_RING 4        // B-fragment register ring of a stream (reads run RING-1 k-steps ahead of their MFMA)
+#endif
+#ifndef NCF_WS8_RINGB
+#define NCF_WS8_RINGB 8       // the same ring in the B waves' layer-2 stream (they have registers to spare and stall behind DMAs)
+#endif
+#ifndef NCF_WS8_STAGE
+#define NCF_WS8_STAGE 0       // 1 = B gathers through registers (global_load_dwordx4 -> ds_write_b128, all compiler-visible) instead of LDS-DMA
+#endif
+#ifndef NCF_WS8_NA
+#define NCF_WS8_NA 2          // row-DMA pieces (of the NCU per unit and pair group) issued by the A wave, after its MFMA stream
+#endif
+#ifndef NCF_WS8_SPREAD
+#define NCF_WS8_SPREAD 3      // B: one row DMA every this many layer-2 k-steps (0 = all DMAs at the head of the phase)
+#endif
+#ifndef NCF_WS8_DIST
+#define NCF_WS8_DIST 5        // D: row DMAs run this many units ahead of layer 1 (3 <= D < NU)
 #endif
 
 namespace ncf {
@@ -36,125 +58,54 @@ namespace ncf {
 template <int K0>
 struct Ws8Layout {
     static constexpr int N1 = 256, N2 = 128;
-    static constexpr int P = 64, CTN = 2;
+    static constexpr int UP = 32;                         // pairs per unit
     static constexpr int NCU = K0 / 64;                   // 128-byte units of the concatenated row
-    static constexpr int CT_BYTES = NCU * 4 * 1024;       // X image of one 32-pair column tile
-    static constexpr int XBUF = CTN * CT_BYTES;
+    static constexpr int UB = NCU * 4 * 1024;             // X image of one unit
+    static constexpr int NU = NCF_WS8_STAGE ? 4 : 6, D = NCF_WS8_STAGE ? 3 : NCF_WS8_DIST;   // X ring slots, DMA distance
     static constexpr int Q1 = K0 / 16, Q2 = N1 / 16;
-    static constexpr int OFF_H1 = 3 * XBUF;
-    static constexpr int H1_BYTES = CTN * Q2 * 1024;
-    static constexpr int OFF_RED = OFF_H1 + H1_BYTES;     // float red[64 pairs][4 neuron slices][2 lane halves]
+    static constexpr int OFF_H1 = NU * UB;
+    static constexpr int H1_HALF = Q2 * 1024;
+    static constexpr int OFF_RED = OFF_H1 + 2 * H1_HALF;  // float red[2][32 pairs][4 neuron slices][2 lane halves]
     static constexpr int OFF_B1 = OFF_RED + 2048;
     static constexpr int OFF_B2 = OFF_B1 + N1 * 4;
     static constexpr int OFF_WL = OFF_B2 + N2 * 4;
-    static constexpr int OFF_IDS = OFF_WL + N2 * 4;       // [8 waves][2 slots][2 tables][8 pairs] int64, twice (lanes 32-63 repeat)
-    static constexpr int OFF_STAMP = OFF_IDS + 8 * 2 * 256;   // diagnostic builds: [8 waves][8 iterations][8 stamps] u64
+    static constexpr int IDS_SLOTS = D + 1;
+    static constexpr int OFF_IDS = OFF_WL + N2 * 4;       // [4 B waves][D+1 slots][2 tables][8 pairs] int64, twice (lanes 32-63 repeat)
+    static constexpr int OFF_STAMP = OFF_IDS + 4 * IDS_SLOTS * 256;   // diagnostic builds: [8 waves][8 phases][8 stamps] u64
     static constexpr int TOTAL = OFF_STAMP + (NCF_BF16_STAMP ? 4096 : 0);
+    static_assert(D >= 3 && D < NU, "DMA distance");
 };
 
 #if NCF_BF16_STAMP
-#define W8_STAMP(k) do { if (a.dbg && lane == 0 && it >= 8 && it < 16) \
-    reinterpret_cast<unsigned long long*>(lds + L::OFF_STAMP)[(w * 8 + (it - 8)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define W8_STAMP(i) do { if (a.dbg && lane == 0 && k >= 16 && k < 24) \
+    reinterpret_cast<unsigned long long*>(lds + L::OFF_STAMP)[(w * 8 + (k - 16)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
-#define W8_STAMP(k) do { } while (0)
+#define W8_STAMP(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#define W8_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
-#define W8_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
-#define W8_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
-
 template <int K0>
 __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, const int64_t* __restrict__ idxA,
                                                                 const int64_t* __restrict__ idxB, float* __restrict__ out,
-                                                                const unsigned char* __restrict__ zeros, int ntiles) {
+                                                                const unsigned char* __restrict__ zeros, int nunits) {
     using L = Ws8Layout<K0>;
-    constexpr int Q1 = L::Q1, Q2 = L::Q2, NCU = L::NCU, N1 = L::N1, N2 = L::N2;
+    constexpr int Q1 = L::Q1, Q2 = L::Q2, NCU = L::NCU, N1 = L::N1, N2 = L::N2, NU = L::NU, D = L::D;
+    constexpr int RING = NCF_WS8_RING, AHEAD = RING - 1;
+    static_assert(Q1 % RING == 0 && Q2 % RING == 0, "the fragment ring keeps its phase from unit to unit");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[L::TOTAL];
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int team = w >> 2, g = w & 3;                      // g: pair group of the DMA pieces AND layer-2 neuron slice
+    const int g = w & 3;                                     // A: layer-1 neuron slice; B: layer-2 neuron slice AND pair group of its DMA pieces
     const int m = lane & 31, h = lane >> 5;
-    const int ncuA = a.EA / 64;
     const int Bp = (int)a.B;                                 // the launcher keeps B below 2^31 for this kernel
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
-    // X image: piece (unit cu, pair group g) = 8 pairs x 128 B, pair-major, the 16-byte chunks of pair p stored at slot
-    // chunk ^ p ^ (g >= 2): a DMA instruction's eight consecutive lanes then cover ONE 128-byte line of one row, and the
-    // B-fragment read of k-step s (lane (m, h) <- chunk 2s+h of pair m) stays a conflict-free ds_read_b128.
-    const int ml = lane >> 3;
-    const int cl = (lane & 7) ^ ml ^ (g >= 2 ? 1 : 0);
-    const int gm = m >> 3;
-    const int key = (m & 7) ^ (gm >= 2 ? 1 : 0);
-    unsigned rd4[4];                                          // reader offset of k-steps with s & 3 = j (the XOR does not commute with +)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rd4[j] = gm * 1024 + (m & 7) * 128 + (((2 * j + h) ^ key) & 7) * 16;
+    const int stride = gridDim.x, bid = blockIdx.x;
+    const int n = (nunits - bid + stride - 1) / stride;      // units of this workgroup: bid, bid + stride, ...  (grid <= nunits)
+    auto unit_pair0 = [&](int k) { return (bid + k * stride) * L::UP; };   // first pair of unit k
 
-    const int stride = gridDim.x;
-    const int tile0 = blockIdx.x;
-    const bool e1 = tile0 + stride < ntiles, e2 = tile0 + 2 * stride < ntiles, e3 = tile0 + 3 * stride < ntiles;
-    const int pw = 8 * w + ml;                               // this lane's pair inside a tile (DMA role)
-
-    // ---- prologue: ids of tiles 0..2 -> row DMAs, THEN the weights (their wait drains the queue once, rows included)
-    int64_t pid[3][2];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int p0 = (tile0 + t * stride) * L::P + pw;
-        const int p = p0 < Bp ? p0 : Bp - 1;
-        pid[t][0] = idxA[p];
-        pid[t][1] = idxB[p];
-    }
-    typedef const unsigned char* RowSrc[2];
-    bool oob_seen = false;
-    auto resolve = [&](RowSrc& src, int p0, int64_t ia, int64_t ib) {
-        const bool okA = (ia >= 0) & (ia < a.rowsA);
-        const bool okB = (ncuA == NCU) | ((ib >= 0) & (ib < a.rowsB));
-        oob_seen |= !(okA & okB) & (p0 < Bp);
-        src[0] = (okA ? reinterpret_cast<const unsigned char*>(a.tabA + ia * a.ldA) : zeros) + cl * 16;
-        src[1] = ((okB & (ncuA < NCU)) ? reinterpret_cast<const unsigned char*>(a.tabB + ib * a.ldB) : zeros) + cl * 16;
-    };
-    auto issue_rows = [&](const RowSrc& src, int slot) {
-#pragma unroll
-        for (int cu = 0; cu < NCU; ++cu) {
-            const bool fromA = cu < ncuA;
-            const unsigned char* gp = (fromA ? src[0] : src[1]) + (fromA ? cu : cu - ncuA) * 128;
-            dma16(gp, lds0 + slot * L::XBUF + team * L::CT_BYTES + (cu * 4 + g) * 1024);
-        }
-    };
-    // a tile's 16 ids per wave (2 tables x 8 pairs) arrive by one dword LDS-DMA (scalar base + 32-bit lane offset)
-    const int ids_dw = lane & 15, ids_tb = (lane >> 4) & 1;
-    auto ids_dma = [&](int t, int slot) {
-        const int p0 = t * L::P + 8 * w + (ids_dw >> 1);
-        const int p = p0 < Bp ? p0 : Bp - 1;
-        const int* gp = reinterpret_cast<const int*>((ids_tb ? idxB : idxA) + p) + (ids_dw & 1);
-        dma4(gp, lds0 + L::OFF_IDS + (w * 2 + slot) * 256);
-    };
-    auto locate = [&](RowSrc& src, int t, int slot) {
-        const unsigned char* q = lds + L::OFF_IDS + (w * 2 + slot) * 256 + ml * 8;
-        const int64_t ia = *reinterpret_cast<const int64_t*>(q);
-        const int64_t ib = *reinterpret_cast<const int64_t*>(q + 64);
-        resolve(src, t * L::P + pw, ia, ib);
-    };
-    {
-        RowSrc s0, s1, s2;
-        resolve(s0, tile0 * L::P + pw, pid[0][0], pid[0][1]);
-        resolve(s1, (tile0 + stride) * L::P + pw, pid[1][0], pid[1][1]);
-        resolve(s2, (tile0 + 2 * stride) * L::P + pw, pid[2][0], pid[2][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_rows(s0, 0);
-        if (e1) issue_rows(s1, 1);
-        if (e3) ids_dma(tile0 + 3 * stride, 1);
-        if (e2) issue_rows(s2, 2);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    u32x4 wa1[Q1], wa2[Q2];
-#pragma unroll
-    for (int s = 0; s < Q1; ++s)
-        wa1[s] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp1) + ((size_t)(s * (N1 / 32) + w) * 64 + lane) * 16);
-#pragma unroll
-    for (int q = 0; q < Q2; ++q)
-        wa2[q] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp2) + ((size_t)(q * (N2 / 32) + g) * 64 + lane) * 16);
+    // biases and the last layer's weights -> LDS (all waves); visible after the barrier that ends each role's prologue
     {
         float* lb1 = reinterpret_cast<float*>(lds + L::OFF_B1);
         float* lb2 = reinterpret_cast<float*>(lds + L::OFF_B2);
@@ -162,22 +113,6 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
         if (threadIdx.x < N1) lb1[threadIdx.x] = a.b1[threadIdx.x];
         if (threadIdx.x < N2) { lb2[threadIdx.x] = a.b2[threadIdx.x]; lwl[threadIdx.x] = a.wl[threadIdx.x]; }
     }
-    const float bl = a.bl[0];
-    // the compiler's own waits for the weights come here (it does not see the DMAs: its vmcnt(N) drains them as well)
-#pragma unroll
-    for (int s = 0; s < Q1; ++s) asm volatile("" ::"v"(wa1[s]));
-#pragma unroll
-    for (int q = 0; q < Q2; ++q) asm volatile("" ::"v"(wa2[q]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wg_barrier();
-
-    // ---- pieces of the steady state ----
-    constexpr int RING = NCF_WS8_RING, AHEAD = RING - 1;
-    const unsigned char* const hbase = lds + L::OFF_H1 + lane * 16;
-    unsigned char* const hwr = lds + L::OFF_H1 + (2 * w) * 1024 + lane * 16;          // this wave's two H1 fragments of a column tile
-    const unsigned char* const wlp = lds + L::OFF_WL + (32 * g + 4 * h) * 4;
-    float* const red = reinterpret_cast<float*>(lds + L::OFF_RED);
-
     auto bias_tile = [&](int off, int neuron0) {
         f32x16 t;
 #pragma unroll
@@ -187,165 +122,347 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
         }
         return t;
     };
-    // layer 1 of column tile ct from the X image of the buffer at byte offset xb; fill(s) = work placed after k-step s
-    auto l1_stream = [&](f32x16& acc, unsigned xb, int ct, auto&& fill) {
-        u32x4 fr[RING];
-        auto xp = [&](int s) { return reinterpret_cast<const u32x4*>(lds + (rd4[s & 3] + xb) + ct * L::CT_BYTES + (s >> 2) * 4096); };
-#pragma unroll
-        for (int j = 0; j < AHEAD; ++j) fr[j] = *xp(j);
-#pragma unroll
-        for (int s = 0; s < Q1; ++s) {
-            if (s + AHEAD < Q1) fr[(s + AHEAD) % RING] = *xp(s + AHEAD);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa1[s]), as_bf16x8(fr[s % RING]), acc, 0, 0, 0);
-            fill(s);
-        }
-    };
-    // layer 2 of column tile ct from H1
-    auto l2_stream = [&](f32x16& acc, int ct, auto&& fill) {
-        u32x4 fr[RING];
-#pragma unroll
-        for (int j = 0; j < AHEAD; ++j) fr[j] = *reinterpret_cast<const u32x4*>(hbase + (ct * Q2 + j) * 1024);
-#pragma unroll
-        for (int q = 0; q < Q2; ++q) {
-            if (q + AHEAD < Q2) fr[(q + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(hbase + (ct * Q2 + q + AHEAD) * 1024);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa2[q]), as_bf16x8(fr[q % RING]), acc, 0, 0, 0);
-            fill(q);
-        }
-    };
-    // ReLU + bf16 of half an accumulator tile -> one ready-made layer-2 B fragment in H1
-    auto pack_half = [&](const f32x16& acc, int ct, int s2) {
-        *reinterpret_cast<bf16x8_t*>(hwr + (ct * Q2 + s2) * 1024) = pack_relu8_int(acc, 8 * s2);
-    };
-    auto dot_quarter = [&](const f32x16& acc, int gq, float part) {
-        const f32x4 ww = *reinterpret_cast<const f32x4*>(wlp + 32 * gq);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) part = fmaf(ww[jj], relu1(acc[4 * gq + jj]), part);
-        return part;
-    };
-    auto publish = [&](float part) { red[((team * 32 + m) * 4 + g) * 2 + h] = part; };
-    auto store_out = [&](int t) {
-        if (w == 0) {
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(red + lane * 8);
-            const f32x4 r1 = *reinterpret_cast<const f32x4*>(red + lane * 8 + 4);
-            const int p = t * L::P + lane;
-            const float v = ((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3])) + bl;
-            if (p < Bp) out[p] = v;
-        }
-    };
-    // positions of the fillers inside a stream of Q k-steps
+    float* const red = reinterpret_cast<float*>(lds + L::OFF_RED);
     auto at = [](int s, int Q, int num, int den) { return s == (Q * num) / den; };
-    const int win = team == 0 ? 2 * g : (2 * g + 5) & 7;      // this wave's DMA window (SIMD partners w, w+4: three or more apart)
 
-    // The two teams run separate loops (a join inside the loop costs accumulator copies).
-    auto run = [&](auto team_tag) {
-        constexpr int TEAM = decltype(team_tag)::value;
-        f32x16 acc1[2], acc2;
-        acc1[0] = bias_tile(L::OFF_B1, 32 * w);
-        if constexpr (TEAM == 1) l1_stream(acc1[0], 0u, 0, [&](int) {});   // peeled: team 1 is one column tile ahead on layer 1
-        acc1[1] = bias_tile(L::OFF_B1, 32 * w);
-        acc2 = bias_tile(L::OFF_B2, 32 * g);                  // team 0, it = 0: the (unused) dot of a tile that does not exist
-        int buf = 0, tile = tile0;
-        for (int it = 0; tile < ntiles; ++it, tile += stride) {
-            const int nbuf = buf == 2 ? 0 : buf + 1, pbuf = buf == 0 ? 2 : buf - 1;
-            const unsigned xb = buf * L::XBUF, xbn = nbuf * L::XBUF;
-            const bool has2 = tile + 2 * stride < ntiles, has3 = tile + 3 * stride < ntiles, has4 = tile + 4 * stride < ntiles;
-            float part = 0.f;
-            // The row DMAs of a tile are spread over the eight waves IN TIME (an LDS-DMA of gathered rows can hold its wave for
-            // hundreds of cycles).  Wave w owns window `win`; windows 0-1 lie in S2(t) (rows of tile t+3 into X(t)'s buffer, free
-            // since alpha(t)), windows 2-7 in S1(t) (rows of tile t+2 into X(t-1)'s buffer): the same cohort of tiles, and in both
-            // cases the wave's newest NCU queue entries at alpha are the rows issued last, so the counted wait is the same.
-            auto fetch = [&](int trow, int tids, bool do_rows, bool do_ids, int slot_x, int slot_ids) {
-                if (do_rows) {
-                    RowSrc src;
-                    locate(src, trow, slot_ids);
-                    if (do_ids) ids_dma(tids, slot_ids ^ 1);
-                    issue_rows(src, slot_x);
-                }
-            };
-            auto win_s2 = [&](int k) { if (win == k) fetch(tile + 3 * stride, tile + 4 * stride, has3, has4, buf, (it + 1) & 1); };
-            auto win_s1 = [&](int k) { if (win == k && it > 0) fetch(tile + 2 * stride, tile + 3 * stride, has2, has3, pbuf, it & 1); };
-            auto dot_fill = [&](int s) {
-                if (s % (Q1 / 4) == Q1 / 4 - 1 && s < Q1 - 1) part = dot_quarter(acc2, s / (Q1 / 4), part);
-                if (s == Q1 - 1) { part = dot_quarter(acc2, 3, part); publish(part); }
-            };
-            auto alpha = [&]() {
-                W8_STAMP(2);
-                if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCU) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                W8_STAMP(3);
-                wg_barrier();
-                W8_STAMP(4);
-            };
-            auto beta = [&]() {
-                W8_STAMP(5);
-                wg_barrier();
-                W8_STAMP(6);
-            };
-            W8_STAMP(0);
-            if constexpr (TEAM == 0) {
-                // ---- S1 ----
-                l1_stream(acc1[0], xb, 0, [&](int s) {
-                    if (s == 0) win_s1(2);
-                    if (at(s, Q1, 6, 8)) win_s1(4);
-                    dot_fill(s);
-                    if (s == Q1 - 1) acc1[1] = bias_tile(L::OFF_B1, 32 * w);
-                });
-                W8_STAMP(1);
-                l1_stream(acc1[1], xb, 1, [&](int s) {
-                    if (at(s, Q1, 1, 4)) pack_half(acc1[0], 0, 0);
-                    if (at(s, Q1, 4, 8)) win_s1(6);
-                    if (at(s, Q1, 3, 4)) pack_half(acc1[0], 0, 1);
-                    if (s == Q1 - 1) acc2 = bias_tile(L::OFF_B2, 32 * g);
-                });
-                alpha();
-                // ---- S2 ----
-                l2_stream(acc2, 0, [&](int q) {
-                    if (q == 0 && it > 0) store_out(tile - stride);
-                    if (q == 1) win_s2(0);
-                    if (at(q, Q2, 1, 4)) pack_half(acc1[1], 1, 0);
-                    if (at(q, Q2, 3, 4)) pack_half(acc1[1], 1, 1);
-                    if (q == Q2 - 1) acc1[0] = bias_tile(L::OFF_B1, 32 * w);
-                });
-                beta();
-            } else {
-                // ---- S1 ----
-                l2_stream(acc2, 1, [&](int q) {
-                    if (at(q, Q2, 1, 4)) pack_half(acc1[0], 0, 0);
-                    if (at(q, Q2, 3, 8)) win_s1(3);
-                    if (at(q, Q2, 3, 4)) pack_half(acc1[0], 0, 1);
-                    if (q == Q2 - 1) acc1[1] = bias_tile(L::OFF_B1, 32 * w);
-                });
-                W8_STAMP(1);
-                l1_stream(acc1[1], xb, 1, [&](int s) {
-                    if (at(s, Q1, 1, 8)) win_s1(5);
-                    if (at(s, Q1, 6, 8)) win_s1(7);
-                    dot_fill(s);
-                    if (s == Q1 - 1) acc1[0] = bias_tile(L::OFF_B1, 32 * w);
-                });
-                alpha();
-                // ---- S2 ----
-                l1_stream(acc1[0], xbn, 0, [&](int s) {
-                    if (at(s, Q1, 1, 4)) pack_half(acc1[1], 1, 0);
-                    if (at(s, Q1, 5, 8)) win_s2(1);
-                    if (at(s, Q1, 3, 4)) pack_half(acc1[1], 1, 1);
-                    if (s == Q1 - 1) acc2 = bias_tile(L::OFF_B2, 32 * g);
-                });
-                beta();
-            }
-            buf = nbuf;
-        }
-        // the last tile: team 1 still owes layer 2 of its column tile; then both teams' dots and the outputs
-        float part = 0.f;
-        if constexpr (TEAM == 1) l2_stream(acc2, 1, [&](int) {});
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) part = dot_quarter(acc2, gq, part);
-        publish(part);
-        wg_barrier();
-        store_out(tile - stride);
+    // ---- the gather: ids and rows by LDS-DMA (helpers shared by both roles; wave g of either role serves pairs 8g .. 8g+7) ----
+    // X image of a unit (EA = EB = K0/2): per table 32 / PP pieces of PP pairs x RC 16-byte chunks — every piece holds WHOLE table
+    // rows, so that one DMA instruction reads PP rows, each by RC consecutive lanes (K0 = 256: 4 rows of 256 B; K0 = 128: 8 rows
+    // of 128 B).  The memory path of a CU takes one random row (or half row) every ~21-24 cycles whatever its length up to a few
+    // lines: a first version that cut 256-byte rows into two 128-byte pieces paid that price twice per row (16 KB per unit in
+    // 2 700 cycles = the whole phase).  Inside a piece, chunk cc of pair m sits at slot cc ^ key(m) of the pair's RC slots, which
+    // keeps the B-fragment read of a k-step (lane (m, h) <- chunk 2s+h of pair m's concatenated row) a conflict-free ds_read_b128:
+    // its 16-lane groups hold 16 different m & 15 (RC = 16: key = m & 15) or 8 different keys in each 128-byte half (RC = 8).
+    constexpr int NJ = NCU / 2;                              // pieces per table, wave and unit
+    constexpr int PP = 8 / NJ;                               // pairs per piece
+    constexpr int RC = 64 / PP;                              // 16-byte chunks per table row
+    constexpr int TSTRIDE = (32 / PP) * 1024;                // bytes between the two tables' pieces inside a unit
+    auto xkey = [](int mm) { return RC == 16 ? (mm & 15) : ((mm & 7) ^ ((mm >> 3) >= 2 ? 1 : 0)); };
+    const int dpp = lane / RC, dpos = lane % RC;             // DMA role: pair dpp of the piece, slot dpos of its row
+    typedef const unsigned char* RowSrc[2][NJ];              // [table][piece]
+    bool oob_seen = false;
+    auto resolve = [&](RowSrc& src, int j, int p0, int64_t ia, int64_t ib) {
+        const int cc = dpos ^ xkey(8 * g + PP * j + dpp);
+        const bool okA = (ia >= 0) & (ia < a.rowsA);
+        const bool okB = (ib >= 0) & (ib < a.rowsB);
+        oob_seen |= !(okA & okB) & (p0 < Bp);
+        src[0][j] = (okA ? reinterpret_cast<const unsigned char*>(a.tabA + ia * a.ldA) : zeros) + cc * 16;
+        src[1][j] = (okB ? reinterpret_cast<const unsigned char*>(a.tabB + ib * a.ldB) : zeros) + cc * 16;
     };
-    if (team == 0) run(std::integral_constant<int, 0>{});
-    else run(std::integral_constant<int, 1>{});
-    if (oob_seen && a.oob) *a.oob = 1;
+    auto issue_row = [&](const RowSrc& src, int slot, int i) {   // piece i of this wave: table i / NJ, pairs 8g + PP (i % NJ) ...
+        const int tb = i / NJ, j = i % NJ;
+        const unsigned char* gp = src[tb][j];
+        if (NCF_WS8_ABLATE == 1) return;
+        if (NCF_WS8_ABLATE == 2) gp = reinterpret_cast<const unsigned char*>(a.tabA) + ((gp - reinterpret_cast<const unsigned char*>(a.tabA)) & 0xFFFF0);
+        if (NCF_WS8_ABLATE == 3) gp = reinterpret_cast<const unsigned char*>(a.tabA) + ((gp - reinterpret_cast<const unsigned char*>(a.tabA)) & 0x3FFFFF0);
+        dma16(gp, lds0 + slot * L::UB + tb * TSTRIDE + (g * NJ + j) * 1024);
+    };
+    auto issue_rows = [&](const RowSrc& src, int slot, int i0, int i1) {
+#pragma unroll
+        for (int i = 0; i < NCU; ++i)
+            if (i >= i0 && i < i1) issue_row(src, slot, i);
+    };
+    constexpr int NA = NCF_WS8_STAGE ? 0 : (NCF_WS8_NA < NCU ? NCF_WS8_NA : NCU - 1);   // row pieces per unit and pair group issued by the A wave (the rest + ids: B)
+    // a unit's 16 ids per B wave (2 tables x 8 pairs) arrive by one dword LDS-DMA; pairs past the end repeat the last pair
+    const int ids_dw = lane & 15, ids_tb = (lane >> 4) & 1;
+    auto ids_dma = [&](int k, int islot) {
+        const int p0 = unit_pair0(k) + 8 * g + (ids_dw >> 1);
+        const int p = p0 < Bp ? p0 : Bp - 1;
+        const int* gp = reinterpret_cast<const int*>((ids_tb ? idxB : idxA) + p) + (ids_dw & 1);
+        dma4(gp, lds0 + L::OFF_IDS + (g * L::IDS_SLOTS + islot) * 256);
+    };
+    auto locate = [&](RowSrc& src, int k, int islot) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned char* q = lds + L::OFF_IDS + (g * L::IDS_SLOTS + islot) * 256 + (PP * j + dpp) * 8;
+            const int64_t ia = *reinterpret_cast<const int64_t*>(q);
+            const int64_t ib = *reinterpret_cast<const int64_t*>(q + 64);
+            resolve(src, j, unit_pair0(k) + 8 * g + PP * j + dpp, ia, ib);
+        }
+    };
+    if (w < 4) {
+        // ================================================= A: layer 1 =================================================
+        if (NCF_WS8_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+        u32x4 wa1[2][Q1];
+#pragma unroll
+        for (int s = 0; s < Q1; ++s)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                wa1[nt][s] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp1) + ((size_t)(s * (N1 / 32) + 2 * g + nt) * 64 + lane) * 16);
+        const float bl = a.bl[0];
+        // reader offsets of the X image (see the gather helpers): the XOR does not commute with +, one offset per s % (RC/2)
+        constexpr int SIG = RC / 2;
+        const int key = xkey(m);
+        unsigned rdx[SIG];
+#pragma unroll
+        for (int j = 0; j < SIG; ++j) rdx[j] = (m / PP) * 1024 + (m % PP) * RC * 16 + (((2 * j + h) ^ key) & (RC - 1)) * 16;
+        unsigned char* const hwr = lds + L::OFF_H1 + (4 * g) * 1024 + lane * 16;   // this wave's four H1 fragments: q = 2 (2g + nt) + s2
+        auto xp = [&](unsigned xb, int s) { return reinterpret_cast<const u32x4*>(lds + (rdx[s % SIG] + xb) + (s / SIG) * TSTRIDE); };
+#pragma unroll
+        for (int s = 0; s < Q1; ++s) asm volatile("" ::"v"(wa1[0][s]), "v"(wa1[1][s]));
+        wg_barrier();                                        // biases in LDS; B has rows(0 .. D-1) landed
+
+        f32x16 acc[2][2];                                    // [unit parity][row tile]
+        u32x4 fr[RING];
+#pragma unroll
+        for (int pk = 0; pk < 2; ++pk)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[pk][nt] = bias_tile(L::OFF_B1, 64 * g + 32 * nt);
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j) fr[j] = *xp(0u, j);
+        auto store_out = [&](int k) {                        // unit k's outputs (wave 0; red[k&1] was published in phase k+3)
+            if (w == 0 && lane < 32) {
+                const float* r = red + ((k & 1) * 32 + lane) * 8;
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(r);
+                const f32x4 r1 = *reinterpret_cast<const f32x4*>(r + 4);
+                const int p = unit_pair0(k) + lane;
+                const float v = ((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3])) + bl;
+                if (p < Bp) out[p] = v;
+            }
+        };
+        // ReLU + bf16 of half an accumulator tile -> one ready-made layer-2 B fragment of H1 half `half`
+        auto pack_frag = [&](const f32x16 (&ac)[2], int half, int f) {
+            if (NCF_WS8_ABLATE == 8) return;
+            const int nt = f >> 1, s2 = f & 1;
+            if (NCF_WS8_ABLATE == 9) { const bf16x8_t v = pack_relu8_int(ac[nt], 8 * s2); asm volatile("" ::"v"(v)); return; }
+            if (NCF_WS8_ABLATE == 10) {
+                const u32x4 raw = {__float_as_uint(ac[nt][8 * s2]), __float_as_uint(ac[nt][8 * s2 + 1]), __float_as_uint(ac[nt][8 * s2 + 2]), __float_as_uint(ac[nt][8 * s2 + 3])};
+                *reinterpret_cast<u32x4*>(hwr + half * L::H1_HALF + (2 * nt + s2) * 1024) = raw;
+                return;
+            }
+            *reinterpret_cast<bf16x8_t*>(hwr + half * L::H1_HALF + (2 * nt + s2) * 1024) = pack_relu8_int(ac[nt], 8 * s2);
+        };
+        int slot = 0, slotA = D % NU, islotA = D % L::IDS_SLOTS;
+        auto phase = [&](int k, auto pk_tag) {
+            constexpr int PK = decltype(pk_tag)::value;
+            const int nslot = slot == NU - 1 ? 0 : slot + 1;
+            const unsigned xb = slot * L::UB, xbn = nslot * L::UB;
+            W8_STAMP(0);
+#pragma unroll
+            for (int s = 0; s < Q1; ++s) {
+                const int j = s + AHEAD;
+                fr[j % RING] = j < Q1 ? *xp(xb, j) : *xp(xbn, j - Q1);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    if (NCF_WS8_ABLATE != 11) acc[PK][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa1[nt][s]), as_bf16x8(fr[s % RING]), acc[PK][nt], 0, 0, 0);
+                    else asm volatile("" ::"v"(fr[s % RING]));
+                // fillers: the previous unit's accumulators -> H1, then their bias for the next unit; outputs of unit k-4
+                if (at(s, Q1, 1, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 0);
+                if (at(s, Q1, 2, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 1);
+                if (at(s, Q1, 3, 8)) { if (k >= 4) store_out(k - 4); }
+                if (at(s, Q1, 4, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 2);
+                if (at(s, Q1, 5, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 3);
+                if (at(s, Q1, 6, 8)) acc[PK ^ 1][0] = bias_tile(L::OFF_B1, 64 * g);
+                if (at(s, Q1, 7, 8)) acc[PK ^ 1][1] = bias_tile(L::OFF_B1, 64 * g + 32);
+            }
+            // A's share of the gather, in the time it would otherwise spend waiting for the B waves at the barrier: the row
+            // pieces cu >= NCU - NA of unit k+D (an LDS-DMA of random rows holds its wave ~150-200 cycles)
+            if (NA > 0) {
+                const bool fetch = k + D < n;
+                if (fetch) {
+                    RowSrc src;
+                    locate(src, k + D, islotA);
+                    issue_rows(src, slotA, NCU - NA, NCU);
+                }
+                // rows(k+2) have landed once only the DMAs of the last D-2 phases are in flight (wave 0 also has one store per
+                // phase in its queue from phase 4 on)
+                if (!fetch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (w != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NA) : "memory");
+                else if (k >= D + 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (NA + 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                slotA = slotA == NU - 1 ? 0 : slotA + 1;
+                islotA = islotA == L::IDS_SLOTS - 1 ? 0 : islotA + 1;
+            }
+            wg_barrier();
+            slot = nslot;
+        };
+        int k = 0;
+        for (; k + 1 < n; k += 2) {
+            phase(k, std::integral_constant<int, 0>{});
+            phase(k + 1, std::integral_constant<int, 1>{});
+        }
+        if (k < n) { phase(k, std::integral_constant<int, 0>{}); ++k; }
+        // drain: phase n packs the last unit; phases n .. n+3 store the last four units' outputs
+        if (n & 1) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) pack_frag(acc[0], 0, f);
+        } else {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) pack_frag(acc[1], 1, f);
+        }
+#pragma unroll
+        for (int dph = 0; dph < 4; ++dph) {
+            if (n + dph >= 4) store_out(n + dph - 4);
+            if (dph < 3) wg_barrier();
+        }
+    } else {
+        // ============================================ B: layer 2, last layer, I/O ============================================
+        if (NCF_WS8_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        // ---- staged gather (NCF_WS8_STAGE): ids and rows by plain loads, two phases ahead in registers, then ds_write_b128 ----
+        struct Ids { int64_t ia[NJ], ib[NJ]; };
+        Ids idsbuf[2];                                       // [parity]: ids of unit k+4 while phase k runs (loaded in phase k-2)
+        u32x4 rowbuf[2][NCU];                                // [parity]: rows of unit k+2 (loaded in phase k-2)
+        auto load_ids = [&](Ids& d, int k) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int p0 = unit_pair0(k) + 8 * g + PP * j + dpp;
+                const int p = p0 < Bp ? p0 : Bp - 1;
+                d.ia[j] = idxA[p];
+                d.ib[j] = idxB[p];
+            }
+        };
+        auto load_rows = [&](u32x4 (&rb)[NCU], const Ids& d, int k) {
+            RowSrc src;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) resolve(src, j, unit_pair0(k) + 8 * g + PP * j + dpp, d.ia[j], d.ib[j]);
+#pragma unroll
+            for (int i = 0; i < NCU; ++i) rb[i] = ldg16(src[i / NJ][i % NJ]);
+        };
+        auto store_rows = [&](const u32x4 (&rb)[NCU], int slot) {
+#pragma unroll
+            for (int i = 0; i < NCU; ++i)
+                *reinterpret_cast<u32x4*>(lds + slot * L::UB + (i / NJ) * TSTRIDE + (g * NJ + i % NJ) * 1024 + lane * 16) = rb[i];
+        };
+        if (NCF_WS8_STAGE) {
+            Ids i0, i1;
+            u32x4 r0[NCU], r1[NCU];
+            load_ids(i0, 0); load_ids(i1, 1); load_ids(idsbuf[0], 2); load_ids(idsbuf[1], 3);
+            load_rows(r0, i0, 0); load_rows(r1, i1, 1);
+            load_rows(rowbuf[0], idsbuf[0], 2); load_rows(rowbuf[1], idsbuf[1], 3);
+            load_ids(idsbuf[0], 4); load_ids(idsbuf[1], 5);
+            store_rows(r0, 0); store_rows(r1, 1);
+        } else {
+            // prologue: units 0..D-1 by direct id loads, ids of units D..2D-1 by DMA; then the weights (their wait drains the queue)
+            {
+                int64_t pid[D][NJ][2];
+    #pragma unroll
+                for (int t = 0; t < D; ++t)
+    #pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int p0 = unit_pair0(t) + 8 * g + PP * j + dpp;
+                        const int p = p0 < Bp ? p0 : Bp - 1;
+                        pid[t][j][0] = idxA[p];
+                        pid[t][j][1] = idxB[p];
+                    }
+    #pragma unroll
+                for (int t = 0; t < D; ++t) {
+                    RowSrc s0;
+    #pragma unroll
+                    for (int j = 0; j < NJ; ++j) resolve(s0, j, unit_pair0(t) + 8 * g + PP * j + dpp, pid[t][j][0], pid[t][j][1]);
+                    if (t < n) issue_rows(s0, t, 0, NCU);
+                }
+    #pragma unroll
+                for (int t = 0; t < D; ++t)
+                    if (D + t < n) ids_dma(D + t, (D + t) % L::IDS_SLOTS);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 wa2[Q2];
+#pragma unroll
+        for (int q = 0; q < Q2; ++q)
+            wa2[q] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp2) + ((size_t)(q * (N2 / 32) + g) * 64 + lane) * 16);
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) asm volatile("" ::"v"(wa2[q]));
+        if (!NCF_WS8_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg_barrier();
+
+        const unsigned char* const hbase = lds + L::OFF_H1 + lane * 16;
+        const unsigned char* const wlp = lds + L::OFF_WL + (32 * g + 4 * h) * 4;
+        f32x16 acc2[2];
+        acc2[0] = bias_tile(L::OFF_B2, 32 * g);
+        acc2[1] = acc2[0];
+        auto l2_stream = [&](f32x16& acc, int half, auto&& fill) {
+            constexpr int RB = NCF_WS8_RINGB, AB = RB - 1;
+            u32x4 fr[RB];
+#pragma unroll
+            for (int j = 0; j < AB; ++j) fr[j] = *reinterpret_cast<const u32x4*>(hbase + half * L::H1_HALF + j * 1024);
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) {
+                if (q + AB < Q2) fr[(q + AB) % RB] = *reinterpret_cast<const u32x4*>(hbase + half * L::H1_HALF + (q + AB) * 1024);
+                if (NCF_WS8_ABLATE != 7 && NCF_WS8_ABLATE != 11) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa2[q]), as_bf16x8(fr[q % RB]), acc, 0, 0, 0);
+                else asm volatile("" ::"v"(fr[q % RB]));
+                fill(q);
+            }
+        };
+        auto dot_quarter = [&](const f32x16& acc, int gq, float part) {
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(wlp + 32 * gq);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) part = fmaf(ww[jj], relu1(acc[4 * gq + jj]), part);
+            return part;
+        };
+        auto publish = [&](int par, float part) { red[((par * 32 + m) * 4 + g) * 2 + h] = part; };
+        int slot = (NCF_WS8_STAGE ? 2 : D) % NU, islot = D % L::IDS_SLOTS, islot2 = (2 * D) % L::IDS_SLOTS;   // of units k+D (rows, ids read) and k+2D (ids written)
+        auto phase = [&](int k, auto pk_tag) {
+            constexpr int PK = decltype(pk_tag)::value;      // parity of k: layer 2 of unit k-2 -> acc2[PK], dot of unit k-3 from acc2[PK^1]
+            const bool fetch = k + D < n && NCF_WS8_ABLATE != 6;
+            float part = 0.f;
+            W8_STAMP(0);
+            RowSrc src;
+            l2_stream(acc2[PK], PK, [&](int q) {
+                if (NCF_WS8_STAGE) {
+                    if (q == 0) {
+                        store_rows(rowbuf[PK], slot);        // unit k+2 (slot of unit k+D with D = 3 ... one behind: see below)
+                        const Ids cur = idsbuf[PK];          // ids of unit k+4
+                        load_ids(idsbuf[PK], k + 6);
+                        load_rows(rowbuf[PK], cur, k + 4);
+                    }
+                } else
+                // the DMAs are spread over the stream: an LDS-DMA of gathered rows holds the wave ~100-200 cycles, during which the
+                // MFMAs it issued just before keep the matrix pipe busy
+                if (NCF_WS8_SPREAD) {
+                    if (q == 0 && fetch) { locate(src, k + D, islot); ids_dma(k + 2 * D, islot2); }
+                    if (q >= 1 && (q - 1) % NCF_WS8_SPREAD == 0 && (q - 1) / NCF_WS8_SPREAD < NCU - NA && fetch) issue_row(src, slot, (q - 1) / NCF_WS8_SPREAD);
+                } else if (q == 0 && fetch) {
+                    locate(src, k + D, islot);
+                    ids_dma(k + 2 * D, islot2);
+                    issue_rows(src, slot, 0, NCU - NA);
+                }
+                if (q == 0) W8_STAMP(4);
+                if (q == 8) W8_STAMP(5);
+                if (q % 4 == 1 && NCF_WS8_ABLATE != 5) part = dot_quarter(acc2[PK ^ 1], q / 4, part);
+                if (q == 14 && NCF_WS8_ABLATE != 5) publish(PK ^ 1, part);
+                if (q == 15) acc2[PK ^ 1] = bias_tile(L::OFF_B2, 32 * g);
+            });
+            W8_STAMP(1);
+            // rows(k+2) have landed once only the DMAs of the last D-2 phases are in flight
+            if (NCF_WS8_STAGE) { }
+            else if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (NCU - NA + 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            W8_STAMP(2);
+            wg_barrier();
+            W8_STAMP(3);
+            slot = slot == NU - 1 ? 0 : slot + 1;
+            islot = islot == L::IDS_SLOTS - 1 ? 0 : islot + 1;
+            islot2 = islot2 == L::IDS_SLOTS - 1 ? 0 : islot2 + 1;
+        };
+        int k = 0;
+        for (; k + 1 < n; k += 2) {
+            phase(k, std::integral_constant<int, 0>{});
+            phase(k + 1, std::integral_constant<int, 1>{});
+        }
+        if (k < n) { phase(k, std::integral_constant<int, 0>{}); ++k; }
+        // drain: phase n: layer 2 of unit n-2, dot of unit n-3; phase n+1: layer 2 of n-1, dot of n-2; phase n+2: dot of n-1
+        auto drain = [&](auto pk_tag, bool l2) {
+            constexpr int PK = decltype(pk_tag)::value;
+            if (l2) l2_stream(acc2[PK], PK, [&](int) {});
+            float part = 0.f;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) part = dot_quarter(acc2[PK ^ 1], gq, part);
+            publish(PK ^ 1, part);
+            acc2[PK ^ 1] = bias_tile(L::OFF_B2, 32 * g);
+            wg_barrier();
+        };
+        if (n & 1) {
+            drain(std::integral_constant<int, 1>{}, true);
+            drain(std::integral_constant<int, 0>{}, true);
+            drain(std::integral_constant<int, 1>{}, false);
+        } else {
+            drain(std::integral_constant<int, 0>{}, true);
+            drain(std::integral_constant<int, 1>{}, true);
+            drain(std::integral_constant<int, 0>{}, false);
+        }
+        if (oob_seen && a.oob) *a.oob = 1;
+    }
 #if NCF_BF16_STAMP
     if (a.dbg) {
         wg_barrier();
@@ -354,15 +471,15 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
 #endif
 }
 
-bool ws8_shape_ok(int K0, int N1, int N2) { return (K0 == 256 || K0 == 128) && N1 == 256 && N2 == 128; }
+bool ws8_shape_ok(int K0, int N1, int N2) { return (K0 == 256 || K0 == 128) && N1 == 256 && N2 == 128; }   // and EA == EB == K0 / 2 (checked by the caller)
 
 void launch_ws8_bf16(int K0, const Bf16Args& a, const unsigned char* zeros, hipStream_t s) {
-    const int ntiles = (int)((a.B + 63) / 64);
-    const int grid = ntiles < num_cus() ? ntiles : num_cus();
+    const int nunits = (int)((a.B + 31) / 32);
+    const int grid = nunits < num_cus() ? nunits : num_cus();
     if (K0 == 256)
-        hipLaunchKernelGGL((score_ws8_bf16_kernel<256>), dim3((unsigned)grid), dim3(512), 0, s, a, a.idxA, a.idxB, a.out, zeros, ntiles);
+        hipLaunchKernelGGL((score_ws8_bf16_kernel<256>), dim3((unsigned)grid), dim3(512), 0, s, a, a.idxA, a.idxB, a.out, zeros, nunits);
     else
-        hipLaunchKernelGGL((score_ws8_bf16_kernel<128>), dim3((unsigned)grid), dim3(512), 0, s, a, a.idxA, a.idxB, a.out, zeros, ntiles);
+        hipLaunchKernelGGL((score_ws8_bf16_kernel<128>), dim3((unsigned)grid), dim3(512), 0, s, a, a.idxA, a.idxB, a.out, zeros, nunits);
 }
 
 }  // namespace ncf

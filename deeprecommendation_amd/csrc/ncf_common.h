@@ -26,7 +26,7 @@ inline int check_launch(const char* what) {
 
 // Process-wide kernel-selection overrides (ncf_set_option; 0 = choose by shape) and the per-device CU count (abi.hip).
 enum {
-    NCF_OPT_BF16_KERNEL = 0,         // 1 = weight-stationary persistent kernel, 2 = slab-streaming kernel
+    NCF_OPT_BF16_KERNEL = 0,         // 1 = 4-wave weight-stationary kernel, 2 = slab-streaming kernel, 3 = 8-wave weight-stationary kernel
     NCF_OPT_LINEAR_KERNEL = 1,       // 1 = one tile per wave (rs), 2 = persistent row-streaming (rsp)
     NCF_OPT_LINEAR_KSLICES = 2,      // 4 / 8 K-slices of the skinny-deep Linear form
     NCF_OPT_ATTN_GROUPED_KERNEL = 3, // 1 = first LDS-broadcast form, 2 = scalar-operand form

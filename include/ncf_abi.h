@@ -55,7 +55,8 @@ const char* ncf_build_arch(void);
 
 /* Process-wide kernel-selection overrides for A/B measurements and for tests that must drive every kernel variant
  * (no counterpart upstream).  0 always means "choose by shape and size" (the default).  Options:
- *   "bf16_kernel"          1 = weight-stationary persistent kernel, 2 = slab-streaming kernel   (ncf_score_fused, NCF_BF16)
+ *   "bf16_kernel"          1 = 4-wave weight-stationary kernel, 2 = slab-streaming kernel, 3 = 8-wave weight-stationary kernel
+ *                          (ncf_score_fused, NCF_BF16; 3 falls back to 1 on shapes it does not take)
  *   "linear_kernel"        1 = one row tile per wave, 2 = persistent row-streaming form          (ncf_mlp_forward / ncf_linear_forward)
  *   "linear_kslices"       4 | 8 = K-slices of the skinny-deep Linear form
  *   "attn_grouped_kernel"  1 = LDS-broadcast form, 2 = scalar-operand form                       (ncf_attn_forward_grouped)

@@ -305,9 +305,9 @@ def test_score_fused_bf16_vs_oracle(gpu, kernel_option, E, hidden, B, kernel):
     """bf16 tables / weights, fp32 accumulate: gathers are bit-exact on the bf16 table; the MLP is compared with the
     oracle evaluated on the same bf16-rounded operands — tolerance 2e-3 relative (builder-defined: BASELINE pins only
     fp32; the residual is fp32 accumulation order plus bf16 re-rounding of hidden activations that sit on a rounding
-    boundary).  Both bf16 kernels (slab-streaming and weight-stationary persistent) run every batch size, including the
-    ones the library's own dispatch would hand to the other kernel: 40 000 / 100 001 / 140 000 pairs give the
-    persistent kernel 3-9 tiles per workgroup with ragged tails."""
+    boundary).  All three bf16 kernels (slab-streaming, 4-wave and 8-wave weight-stationary) run every batch size, including
+    the ones the library's own dispatch would hand to another kernel: 40 000 / 100 001 / 140 000 pairs give the persistent
+    kernels 3-17 tiles (units) per workgroup with ragged tails; a one-hidden-layer MLP sends "ws8" to the 4-wave kernel."""
     from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
     from deeprecommendation_amd import native
     if kernel == "auto":
@@ -333,6 +333,52 @@ def test_score_fused_bf16_vs_oracle(gpu, kernel_option, E, hidden, B, kernel):
     tu = m._table("user", m.user_embeddings[0])
     assert torch.equal(tu.cpu(), O.embedding_table(state["user_embeddings.0.weight"], state["user_embeddings.0.bias"]).to(torch.bfloat16))
     assert torch.equal(native.gather_concat(tu, u.to(gpu)), tu[u.to(gpu)])
+
+
+@pytest.mark.parametrize("units_per_wg", [1, 2, 3, 4, 5, 6, 7, 8, 13])
+@pytest.mark.parametrize("ragged", [0, 1, 31, 33])
+def test_score_fused_bf16_ws8_pipeline_depths(native, gpu, kernel_option, units_per_wg, ragged):
+    """The 8-wave kernel's software pipeline is 4 phases deep (layer 1 -> pack -> layer 2 -> dot -> store) and its row DMAs run 5
+    units ahead: every count of 32-pair units per workgroup from 1 up (prologue-only, shorter than the pipeline, steady state),
+    with ragged tails, against the 4-wave kernel on the same inputs (same MFMA chains: equal to fp32 summation order)."""
+    cus = torch.cuda.get_device_properties(gpu).multi_processor_count
+    B = 32 * cus * (units_per_wg - 1) + 32 * (cus // 2 + 1) + ragged
+    g = torch.Generator(device=gpu).manual_seed(units_per_wg * 100 + ragged)
+    E, U, I = 128, 50000, 20000
+    tu = (torch.randn(U, E, device=gpu, generator=g) * 0.05).to(torch.bfloat16)
+    ti = (torch.randn(I, E, device=gpu, generator=g) * 0.05).to(torch.bfloat16)
+    dims = [2 * E, 256, 128, 1]
+    ws = [torch.randn(dims[k + 1], dims[k], device=gpu, generator=g) / dims[k] ** 0.5 for k in range(3)]
+    bs = [torch.randn(dims[k + 1], device=gpu, generator=g) * 0.1 for k in range(3)]
+    packed = native.PackedMLP(ws, bs, dtype=torch.bfloat16)
+    iu = torch.randint(0, U, (B,), device=gpu, generator=g)
+    ii = torch.randint(0, I, (B,), device=gpu, generator=g)
+    outs = {}
+    for kernel in ("ws", "ws8"):
+        kernel_option("bf16_kernel", kernel)
+        outs[kernel] = native.score_fused(tu, iu, ti, ii, packed).clone()
+    assert_close(outs["ws8"], outs["ws"].cpu(), rtol=1e-5)
+    native.check_oob(gpu)
+
+
+def test_score_fused_bf16_ws8_falls_back_on_other_shapes(native, gpu, kernel_option):
+    """Tables of different widths (EA != EB) are not the 8-wave kernel's shape: the option then selects the 4-wave kernel."""
+    g = torch.Generator(device=gpu).manual_seed(3)
+    EA, EB, B = 192, 64, 5000
+    ta = (torch.randn(900, EA, device=gpu, generator=g) * 0.05).to(torch.bfloat16)
+    tb = (torch.randn(400, EB, device=gpu, generator=g) * 0.05).to(torch.bfloat16)
+    dims = [EA + EB, 256, 128, 1]
+    ws = [torch.randn(dims[k + 1], dims[k], device=gpu, generator=g) / dims[k] ** 0.5 for k in range(3)]
+    bs = [torch.randn(dims[k + 1], device=gpu, generator=g) * 0.1 for k in range(3)]
+    packed = native.PackedMLP(ws, bs, dtype=torch.bfloat16)
+    ia = torch.randint(0, 900, (B,), device=gpu, generator=g)
+    ib = torch.randint(0, 400, (B,), device=gpu, generator=g)
+    outs = {}
+    for kernel in ("stream", "ws", "ws8", "auto"):
+        kernel_option("bf16_kernel", kernel)
+        outs[kernel] = native.score_fused(ta, ia, tb, ib, packed).clone()
+    assert torch.equal(outs["ws8"], outs["ws"]) and torch.equal(outs["auto"], outs["ws"])
+    assert_close(outs["ws"], outs["stream"].cpu(), rtol=2e-3)
 
 
 @pytest.mark.parametrize("kernel", ["stream", "ws", "ws8"])

@@ -23,6 +23,11 @@ def main():
     dims = [256, 256, 128, 1]
     ws = [torch.randn(dims[i + 1], dims[i], device=dev, generator=g) / dims[i] ** 0.5 for i in range(3)]
     bs = [torch.randn(dims[i + 1], device=dev, generator=g) * 0.1 for i in range(3)]
+    if os.environ.get("AB_ZERO") == "1":      # all-zero operands: same cycles, far less switching power (a power / clock check)
+        tu.zero_(); ti.zero_()
+        ws = [w * 0 for w in ws]
+    if os.environ.get("AB_ZERO") == "2":      # zero tables only
+        tu.zero_(); ti.zero_()
     packed = native.PackedMLP(ws, bs, dtype=torch.bfloat16)
     flop = 2 * (256 * 256 + 256 * 128 + 128)
     for Bsz in sizes:
@@ -37,7 +42,7 @@ def main():
         for k in kernels[1:]:
             d = (outs[k] - outs[kernels[0]]).abs().max().item()
             print(f"B={Bsz}: max |{k} - {kernels[0]}| = {d:.3e} (scale {outs[kernels[0]].abs().max().item():.3f})", flush=True)
-        reps = max(10, min(200, int(2e7 / Bsz)))
+        reps = max(10, min(200, int(6e7 / Bsz)))
         times = {k: [] for k in kernels}
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for r in range(6):

@@ -36,20 +36,18 @@ def main():
     native.score_fused(tu, iu, ti, ii, packed, out=out)
     torch.cuda.synchronize()
     lib.ncf_dev_set_bf16_debug_buffer(None)
-    d = dbg.view(256, 8, 8, 8).cpu().double()       # block, wave, iteration 8..15, stamp
-    names = ["stream 1", "stream 2", "vmcnt wait", "alpha wait", "S2 stream", "beta wait"]
-    for team in (0, 1):
-        x = d[:, 4 * team:4 * team + 4]
-        seg = x[..., 1:7] - x[..., 0:6]
-        tilec = x[:, :, 1:, 0] - x[:, :, :-1, 0]
-        print(f"team {team}: tile {tilec.median().item():.0f} cycles (mean {tilec.mean().item():.0f}); " +
-              ", ".join(f"{n} {seg[..., k].median().item():.0f}/{seg[..., k].mean().item():.0f}" for k, n in enumerate(names)))
-    # per-wave picture of one block
-    b = 7
-    for w in range(8):
-        x = d[b, w]
-        seg = (x[:, 1:7] - x[:, 0:6]).mean(0)
-        print(f"block {b} wave {w}: " + " ".join(f"{v:.0f}" for v in seg.tolist()), " start skew vs wave 0:", (x[:, 0] - d[b, 0, :, 0]).mean().item())
+    d = dbg.view(256, 8, 8, 8).cpu().double()       # block, wave, phase 16..23, stamp
+    a, b = d[:, :4], d[:, 4:]
+    per = a[:, :, 1:, 0] - a[:, :, :-1, 0]
+    print(f"phase period (A waves, stamp 0 only): median {per.median().item():.0f} cycles, mean {per.mean().item():.0f}")
+    names = [("head (locate + DMAs at q = 0)", 0, 4), ("k-steps 1..8", 4, 5), ("k-steps 9..15", 5, 1), ("vmcnt wait", 1, 2), ("barrier wait", 2, 3)]
+    for nm, i0, i1 in names:
+        x = b[..., i1] - b[..., i0]
+        print(f"B {nm}: median {x.median().item():.0f}, mean {x.mean().item():.0f}")
+    x = b[:, :, 1:, 0] - b[:, :, :-1, 3]
+    print(f"B barrier exit -> next phase start: median {x.median().item():.0f}")
+    skew = b[:, :, :, 0].mean(1) - a[:, :, :, 0].mean(1)
+    print(f"B phase start - A phase start: median {skew.median().item():.0f}")
 
 
 if __name__ == "__main__":
