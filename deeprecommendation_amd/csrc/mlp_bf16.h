@@ -20,6 +20,7 @@ struct Bf16Args {
     int64_t B; int EA;
     const unsigned short* Wp1; const float* b1;
     const unsigned short* Wp2; const float* b2;
+    const unsigned short* Wp1m; const unsigned short* Wp2m;   // the same weights as 16x16x32 A fragments (8-wave kernel), or null
     const float* wl; const float* bl;
     float* out; int32_t* oob;
 #if NCF_BF16_STAMP
@@ -33,6 +34,21 @@ __device__ __forceinline__ bf16x8_t as_bf16x8(u32x4 v) {
     union { u32x4 u; bf16x8_t b; } c;
     c.u = v;
     return c.b;
+}
+
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+// two 16x16 accumulator tiles (4 + 4 registers) -> one 16x16x32 B fragment: RNE to bf16, ReLU on the packed pairs as int16
+__device__ __forceinline__ bf16x8_t pack_relu4x2_int(const f32x4& lo, const f32x4& hi) {
+    union { bf16x8_t b; s16x2_t s[4]; } r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4& t = j < 2 ? lo : hi;
+        f32x2 v = {t[2 * (j & 1)], t[2 * (j & 1) + 1]};
+        union { bf16x2_t b; s16x2_t s; } p;
+        p.b = __builtin_convertvector(v, bf16x2_t);
+        r.s[j] = __builtin_elementwise_max(p.s, (s16x2_t){0, 0});
+    }
+    return r.b;
 }
 
 // relu + round-to-nearest-even to bf16 of 8 accumulator registers -> one MFMA B fragment
@@ -51,7 +67,6 @@ __device__ __forceinline__ bf16x8_t pack_relu8(const f32x16& acc, int base) {
 // the same fragment with the ReLU applied AFTER the rounding, on the packed pairs as signed 16-bit integers (a negative
 // bf16 is a negative int16; rounding keeps the sign, so the result is bit-identical): 4 cvt + 4 v_pk_max_i16
 // instead of 16 v_max_f32 + 4 cvt — this matters where the conversion has to hide in MFMA issue gaps
-typedef short s16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8_t pack_relu8_int(const f32x16& acc, int base) {
     union { bf16x8_t b; s16x2_t s[4]; } r;
 #pragma unroll

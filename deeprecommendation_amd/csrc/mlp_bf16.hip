@@ -699,17 +699,29 @@ __global__ __launch_bounds__(256, 1) void score_ws_bf16_kernel(Bf16Args a, const
 // Wp[q][nt][lane][8] (bf16, RNE from fp32) with
 //   natural order   (layer 1): element j = W[32nt + (lane&31)][16q + 8(lane>>5) + j]
 //   permuted order  (layer 2): element j = W[32nt + (lane&31)][32(q>>1) + 16(q&1) + 8(j>>2) + 4(lane>>5) + (j&3)]
-__global__ void pack_weight_bf16_kernel(const float* __restrict__ W, int N, int K, int permuted, unsigned short* __restrict__ Wp) {
+// and, for the 16x16x32 MFMA shape of the 8-wave kernel (modes 2 / 3; nt counts 16-row tiles, q 32-wide k-steps):
+//   natural order   (layer 1): element j = W[16nt + (lane&15)][32q + 8(lane>>4) + j]
+//   permuted order  (layer 2): element j = W[16nt + (lane&15)][32q + 16(j>>2) + 4(lane>>4) + (j&3)]
+__global__ void pack_weight_bf16_kernel(const float* __restrict__ W, int N, int K, int mode, unsigned short* __restrict__ Wp) {
     const int64_t total = (int64_t)N * K;
-    const int NT = N / 32;
+    const int rows = mode >= 2 ? 16 : 32;
+    const int NT = N / rows;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(o & 7);
         const int lane = (int)((o >> 3) & 63);
         const int64_t t = o >> 9;  // q*NT + nt
         const int nt = (int)(t % NT), q = (int)(t / NT);
-        const int h = lane >> 5;
-        const int k = permuted ? 32 * (q >> 1) + 16 * (q & 1) + 8 * (j >> 2) + 4 * h + (j & 3) : 16 * q + 8 * h + j;
-        const float v = W[(int64_t)(32 * nt + (lane & 31)) * K + k];
+        int k, row;
+        if (mode < 2) {
+            const int h = lane >> 5;
+            k = mode ? 32 * (q >> 1) + 16 * (q & 1) + 8 * (j >> 2) + 4 * h + (j & 3) : 16 * q + 8 * h + j;
+            row = 32 * nt + (lane & 31);
+        } else {
+            const int kg = lane >> 4;
+            k = mode == 3 ? 32 * q + 16 * (j >> 2) + 4 * kg + (j & 3) : 32 * q + 8 * kg + j;
+            row = 16 * nt + (lane & 15);
+        }
+        const float v = W[(int64_t)row * K + k];
         const __bf16 b = (__bf16)v;  // round-to-nearest-even (v_cvt_pk_bf16_f32)
         Wp[o] = *reinterpret_cast<const unsigned short*>(&b);
     }
@@ -721,7 +733,7 @@ __global__ void copy_or_zero_f32_kernel(const float* __restrict__ src, int n, fl
 }
 
 struct Bf16Blob {
-    size_t wp1, b1, wp2, b2, wl, bl, zeros, total;  // byte offsets
+    size_t wp1, b1, wp2, b2, wl, bl, zeros, wp1m, wp2m, total;  // byte offsets (wp1m / wp2m: 16x16x32 fragments, three-layer MLPs only)
 };
 static Bf16Blob bf16_blob(const int* dims, int n_layers) {
     Bf16Blob L{};
@@ -738,7 +750,11 @@ static Bf16Blob bf16_blob(const int* dims, int n_layers) {
     }
     L.wl = off; off += last * 4;
     L.bl = off; off += 16;
-    L.zeros = off; off += 512;  // source of the rows of out-of-range ids (weight-stationary kernel: 4 x 128-byte units)
+    L.zeros = off; off += 512;  // source of the rows of out-of-range ids (weight-stationary kernels: 4 x 128-byte units)
+    if (n_layers == 3) {
+        L.wp1m = off; off += N1 * K0 * 2;
+        L.wp2m = off; off += (size_t)dims[2] * N1 * 2;
+    }
     L.total = off;
     return L;
 }
@@ -795,6 +811,8 @@ int bf16_pack(int n_layers, const int* dims, const void* const* W, const void* c
     int last = dims[1];
     if (n_layers == 3) {
         hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(256), dim3(256), 0, s, (const float*)W[1], dims[2], dims[1], 1, (unsigned short*)(P + L.wp2));
+        hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(256), dim3(256), 0, s, (const float*)W[0], dims[1], dims[0], 2, (unsigned short*)(P + L.wp1m));
+        hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(256), dim3(256), 0, s, (const float*)W[1], dims[2], dims[1], 3, (unsigned short*)(P + L.wp2m));
         hipLaunchKernelGGL(copy_or_zero_f32_kernel, dim3((dims[2] + 255) / 256), dim3(256), 0, s, bias(1), dims[2], (float*)(P + L.b2));
         last = dims[2];
     }
@@ -818,6 +836,8 @@ int bf16_score(const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, i
     a.Wp1 = (const unsigned short*)(P + L.wp1); a.b1 = (const float*)(P + L.b1);
     a.Wp2 = n_layers == 3 ? (const unsigned short*)(P + L.wp2) : nullptr;
     a.b2 = n_layers == 3 ? (const float*)(P + L.b2) : nullptr;
+    a.Wp1m = n_layers == 3 ? (const unsigned short*)(P + L.wp1m) : nullptr;
+    a.Wp2m = n_layers == 3 ? (const unsigned short*)(P + L.wp2m) : nullptr;
     a.wl = (const float*)(P + L.wl); a.bl = (const float*)(P + L.bl);
     a.out = out; a.oob = oob;
 #if NCF_BF16_STAMP

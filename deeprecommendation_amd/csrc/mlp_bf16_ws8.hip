@@ -28,6 +28,9 @@
 #include "mlp_bf16.h"
 #include <type_traits>
 
+#ifndef NCF_WS8_M16
+#define NCF_WS8_M16 1         // 1 = v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on it), 0 = v_mfma_f32_32x32x16_bf16
+#endif
 #ifndef NCF_WS8_ABLATE
 #define NCF_WS8_ABLATE 0      // diagnostics: 1 = no row DMAs, 2 / 3 = rows from a 1 MiB / 64 MiB window of table A
 #endif
@@ -66,7 +69,7 @@ struct Ws8Layout {
     static constexpr int OFF_H1 = NU * UB;
     static constexpr int H1_HALF = Q2 * 1024;
     static constexpr int OFF_RED = OFF_H1 + 2 * H1_HALF;  // float red[2][32 pairs][4 neuron slices][2 lane halves]
-    static constexpr int OFF_B1 = OFF_RED + 2048;
+    static constexpr int OFF_B1 = OFF_RED + 4096;         // (16x16x32 form: [2][32 pairs][4 slices][4 lane groups])
     static constexpr int OFF_B2 = OFF_B1 + N1 * 4;
     static constexpr int OFF_WL = OFF_B2 + N2 * 4;
     static constexpr int IDS_SLOTS = D + 1;
@@ -85,7 +88,7 @@ struct Ws8Layout {
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int K0>
+template <int K0, bool M16>
 __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, const int64_t* __restrict__ idxA,
                                                                 const int64_t* __restrict__ idxB, float* __restrict__ out,
                                                                 const unsigned char* __restrict__ zeros, int nunits) {
@@ -183,117 +186,236 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
     if (w < 4) {
         // ================================================= A: layer 1 =================================================
         if (NCF_WS8_PRIO == 2) __builtin_amdgcn_s_setprio(1);
-        u32x4 wa1[2][Q1];
+        if constexpr (M16) {
+            // ---- 16x16x32 form: 4 row tiles x 2 column tiles of 16 pairs; a unit's 2 KS1 X fragments feed 4 MFMAs each ----
+            constexpr int KS1 = K0 / 32, KS2 = N1 / 32, NF = 2 * KS1;
+            static_assert(NF % RING == 0, "the fragment ring keeps its phase from unit to unit");
+            const int p16 = lane & 15, kg = lane >> 4;
+            u32x4 wa[4][KS1];
 #pragma unroll
-        for (int s = 0; s < Q1; ++s)
+            for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                wa1[nt][s] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp1) + ((size_t)(s * (N1 / 32) + 2 * g + nt) * 64 + lane) * 16);
-        const float bl = a.bl[0];
-        // reader offsets of the X image (see the gather helpers): the XOR does not commute with +, one offset per s % (RC/2)
-        constexpr int SIG = RC / 2;
-        const int key = xkey(m);
-        unsigned rdx[SIG];
+                for (int rt = 0; rt < 4; ++rt)
+                    wa[rt][ks] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp1m) + ((size_t)(ks * (N1 / 16) + 4 * g + rt) * 64 + lane) * 16);
+            const float bl = a.bl[0];
+            // reader offsets: lane (p16, kg) takes chunk 4 ks + kg of pair 16 ct + p16; one offset per column tile and ks % (RC / 4)
+            constexpr int SG = RC / 4;
+            unsigned rdx[2][SG];
 #pragma unroll
-        for (int j = 0; j < SIG; ++j) rdx[j] = (m / PP) * 1024 + (m % PP) * RC * 16 + (((2 * j + h) ^ key) & (RC - 1)) * 16;
-        unsigned char* const hwr = lds + L::OFF_H1 + (4 * g) * 1024 + lane * 16;   // this wave's four H1 fragments: q = 2 (2g + nt) + s2
-        auto xp = [&](unsigned xb, int s) { return reinterpret_cast<const u32x4*>(lds + (rdx[s % SIG] + xb) + (s / SIG) * TSTRIDE); };
+            for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int s = 0; s < Q1; ++s) asm volatile("" ::"v"(wa1[0][s]), "v"(wa1[1][s]));
-        wg_barrier();                                        // biases in LDS; B has rows(0 .. D-1) landed
+                for (int j = 0; j < SG; ++j) {
+                    const int mm = 16 * ct + p16;
+                    rdx[ct][j] = (mm / PP) * 1024 + (mm % PP) * RC * 16 + (((4 * j + kg) ^ xkey(mm)) & (RC - 1)) * 16;
+                }
+            auto xp = [&](unsigned xb, int j) {              // fragment j of a unit: column tile j / KS1, k-step j % KS1
+                const int ct = j / KS1, ks = j % KS1;
+                return reinterpret_cast<const u32x4*>(lds + (rdx[ct][ks % SG] + xb) + (ks / SG) * TSTRIDE);
+            };
+            unsigned char* const hwr = lds + L::OFF_H1 + (2 * g) * 1024 + lane * 16;   // fragments (ct, ks2 = 2g + e) at (ct KS2 + 2g + e) KiB
+            const unsigned char* const b1p = lds + L::OFF_B1 + (64 * g + 4 * kg) * 4;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) asm volatile("" ::"v"(wa[0][ks]), "v"(wa[1][ks]), "v"(wa[2][ks]), "v"(wa[3][ks]));
+            wg_barrier();                                    // biases in LDS; B has rows(0 .. D-1) landed
 
-        f32x16 acc[2][2];                                    // [unit parity][row tile]
-        u32x4 fr[RING];
+            f32x4 acc[2][4][2];                              // [unit parity][row tile][column tile]
+            u32x4 fr[RING];
+            auto bias_init = [&](f32x4 (&ac)[4][2], int rt) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1p + 64 * rt);
+                ac[rt][0] = bb; ac[rt][1] = bb;
+            };
 #pragma unroll
-        for (int pk = 0; pk < 2; ++pk)
+            for (int pk = 0; pk < 2; ++pk)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[pk][nt] = bias_tile(L::OFF_B1, 64 * g + 32 * nt);
+                for (int rt = 0; rt < 4; ++rt) bias_init(acc[pk], rt);
 #pragma unroll
-        for (int j = 0; j < AHEAD; ++j) fr[j] = *xp(0u, j);
-        auto store_out = [&](int k) {                        // unit k's outputs (wave 0; red[k&1] was published in phase k+3)
-            if (w == 0 && lane < 32) {
-                const float* r = red + ((k & 1) * 32 + lane) * 8;
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(r);
-                const f32x4 r1 = *reinterpret_cast<const f32x4*>(r + 4);
-                const int p = unit_pair0(k) + lane;
-                const float v = ((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3])) + bl;
-                if (p < Bp) out[p] = v;
+            for (int j = 0; j < AHEAD; ++j) fr[j] = *xp(0u, j);
+            auto store_out = [&](int k) {                    // unit k's outputs (wave 0; red[k&1] was published in phase k+3)
+                if (w == 0 && lane < 32) {
+                    const float* r = red + ((k & 1) * 32 + lane) * 16;
+                    f32x4 t = *reinterpret_cast<const f32x4*>(r);
+#pragma unroll
+                    for (int i = 1; i < 4; ++i) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(r + 4 * i);
+                        t[0] += u[0]; t[1] += u[1]; t[2] += u[2]; t[3] += u[3];
+                    }
+                    const int p = unit_pair0(k) + lane;
+                    if (p < Bp) out[p] = ((t[0] + t[1]) + (t[2] + t[3])) + bl;
+                }
+            };
+            // ReLU + bf16 of two 16-neuron tiles -> one layer-2 B fragment (column tile ct, k-step 2g + e) of H1 half `half`
+            auto pack_frag = [&](const f32x4 (&ac)[4][2], int half, int f) {
+                const int ct = f >> 1, e = f & 1;
+                *reinterpret_cast<bf16x8_t*>(hwr + half * L::H1_HALF + (ct * KS2 + e) * 1024) = pack_relu4x2_int(ac[2 * e][ct], ac[2 * e + 1][ct]);
+            };
+            int slot = 0, slotA = D % NU, islotA = D % L::IDS_SLOTS;
+            auto phase = [&](int k, auto pk_tag) {
+                constexpr int PK = decltype(pk_tag)::value;
+                const int nslot = slot == NU - 1 ? 0 : slot + 1;
+                const unsigned xb = slot * L::UB, xbn = nslot * L::UB;
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const int jn = j + AHEAD;
+                    fr[jn % RING] = jn < NF ? *xp(xb, jn) : *xp(xbn, jn - NF);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt)
+                        acc[PK][rt][j / KS1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wa[rt][j % KS1]), as_bf16x8(fr[j % RING]), acc[PK][rt][j / KS1], 0, 0, 0);
+                    if (at(j, NF, 1, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 0);
+                    if (at(j, NF, 2, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 1);
+                    if (at(j, NF, 3, 8)) { if (k >= 4) store_out(k - 4); }
+                    if (at(j, NF, 4, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 2);
+                    if (at(j, NF, 5, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 3);
+                    if (at(j, NF, 6, 8)) { bias_init(acc[PK ^ 1], 0); bias_init(acc[PK ^ 1], 1); }
+                    if (at(j, NF, 7, 8)) { bias_init(acc[PK ^ 1], 2); bias_init(acc[PK ^ 1], 3); }
+                }
+                if (NA > 0) {
+                    const bool fetch = k + D < n;
+                    if (fetch) {
+                        RowSrc src;
+                        locate(src, k + D, islotA);
+                        issue_rows(src, slotA, NCU - NA, NCU);
+                    }
+                    if (!fetch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (w != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NA) : "memory");
+                    else if (k >= D + 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (NA + 1)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    slotA = slotA == NU - 1 ? 0 : slotA + 1;
+                    islotA = islotA == L::IDS_SLOTS - 1 ? 0 : islotA + 1;
+                }
+                wg_barrier();
+                slot = nslot;
+            };
+            int k = 0;
+            for (; k + 1 < n; k += 2) {
+                phase(k, std::integral_constant<int, 0>{});
+                phase(k + 1, std::integral_constant<int, 1>{});
             }
-        };
-        // ReLU + bf16 of half an accumulator tile -> one ready-made layer-2 B fragment of H1 half `half`
-        auto pack_frag = [&](const f32x16 (&ac)[2], int half, int f) {
-            if (NCF_WS8_ABLATE == 8) return;
-            const int nt = f >> 1, s2 = f & 1;
-            if (NCF_WS8_ABLATE == 9) { const bf16x8_t v = pack_relu8_int(ac[nt], 8 * s2); asm volatile("" ::"v"(v)); return; }
-            if (NCF_WS8_ABLATE == 10) {
-                const u32x4 raw = {__float_as_uint(ac[nt][8 * s2]), __float_as_uint(ac[nt][8 * s2 + 1]), __float_as_uint(ac[nt][8 * s2 + 2]), __float_as_uint(ac[nt][8 * s2 + 3])};
-                *reinterpret_cast<u32x4*>(hwr + half * L::H1_HALF + (2 * nt + s2) * 1024) = raw;
-                return;
-            }
-            *reinterpret_cast<bf16x8_t*>(hwr + half * L::H1_HALF + (2 * nt + s2) * 1024) = pack_relu8_int(ac[nt], 8 * s2);
-        };
-        int slot = 0, slotA = D % NU, islotA = D % L::IDS_SLOTS;
-        auto phase = [&](int k, auto pk_tag) {
-            constexpr int PK = decltype(pk_tag)::value;
-            const int nslot = slot == NU - 1 ? 0 : slot + 1;
-            const unsigned xb = slot * L::UB, xbn = nslot * L::UB;
-            W8_STAMP(0);
+            if (k < n) { phase(k, std::integral_constant<int, 0>{}); ++k; }
+            if (n & 1) {
 #pragma unroll
-            for (int s = 0; s < Q1; ++s) {
-                const int j = s + AHEAD;
-                fr[j % RING] = j < Q1 ? *xp(xb, j) : *xp(xbn, j - Q1);
+                for (int f = 0; f < 4; ++f) pack_frag(acc[0], 0, f);
+            } else {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) pack_frag(acc[1], 1, f);
+            }
+#pragma unroll
+            for (int dph = 0; dph < 4; ++dph) {
+                if (n + dph >= 4) store_out(n + dph - 4);
+                if (dph < 3) wg_barrier();
+            }
+        } else {
+            u32x4 wa1[2][Q1];
+#pragma unroll
+            for (int s = 0; s < Q1; ++s)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    if (NCF_WS8_ABLATE != 11) acc[PK][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa1[nt][s]), as_bf16x8(fr[s % RING]), acc[PK][nt], 0, 0, 0);
-                    else asm volatile("" ::"v"(fr[s % RING]));
-                // fillers: the previous unit's accumulators -> H1, then their bias for the next unit; outputs of unit k-4
-                if (at(s, Q1, 1, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 0);
-                if (at(s, Q1, 2, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 1);
-                if (at(s, Q1, 3, 8)) { if (k >= 4) store_out(k - 4); }
-                if (at(s, Q1, 4, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 2);
-                if (at(s, Q1, 5, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 3);
-                if (at(s, Q1, 6, 8)) acc[PK ^ 1][0] = bias_tile(L::OFF_B1, 64 * g);
-                if (at(s, Q1, 7, 8)) acc[PK ^ 1][1] = bias_tile(L::OFF_B1, 64 * g + 32);
-            }
-            // A's share of the gather, in the time it would otherwise spend waiting for the B waves at the barrier: the row
-            // pieces cu >= NCU - NA of unit k+D (an LDS-DMA of random rows holds its wave ~150-200 cycles)
-            if (NA > 0) {
-                const bool fetch = k + D < n;
-                if (fetch) {
-                    RowSrc src;
-                    locate(src, k + D, islotA);
-                    issue_rows(src, slotA, NCU - NA, NCU);
+                    wa1[nt][s] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp1) + ((size_t)(s * (N1 / 32) + 2 * g + nt) * 64 + lane) * 16);
+            const float bl = a.bl[0];
+            // reader offsets of the X image (see the gather helpers): the XOR does not commute with +, one offset per s % (RC/2)
+            constexpr int SIG = RC / 2;
+            const int key = xkey(m);
+            unsigned rdx[SIG];
+#pragma unroll
+            for (int j = 0; j < SIG; ++j) rdx[j] = (m / PP) * 1024 + (m % PP) * RC * 16 + (((2 * j + h) ^ key) & (RC - 1)) * 16;
+            unsigned char* const hwr = lds + L::OFF_H1 + (4 * g) * 1024 + lane * 16;   // this wave's four H1 fragments: q = 2 (2g + nt) + s2
+            auto xp = [&](unsigned xb, int s) { return reinterpret_cast<const u32x4*>(lds + (rdx[s % SIG] + xb) + (s / SIG) * TSTRIDE); };
+#pragma unroll
+            for (int s = 0; s < Q1; ++s) asm volatile("" ::"v"(wa1[0][s]), "v"(wa1[1][s]));
+            wg_barrier();                                        // biases in LDS; B has rows(0 .. D-1) landed
+
+            f32x16 acc[2][2];                                    // [unit parity][row tile]
+            u32x4 fr[RING];
+#pragma unroll
+            for (int pk = 0; pk < 2; ++pk)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[pk][nt] = bias_tile(L::OFF_B1, 64 * g + 32 * nt);
+#pragma unroll
+            for (int j = 0; j < AHEAD; ++j) fr[j] = *xp(0u, j);
+            auto store_out = [&](int k) {                        // unit k's outputs (wave 0; red[k&1] was published in phase k+3)
+                if (w == 0 && lane < 32) {
+                    const float* r = red + ((k & 1) * 32 + lane) * 8;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(r);
+                    const f32x4 r1 = *reinterpret_cast<const f32x4*>(r + 4);
+                    const int p = unit_pair0(k) + lane;
+                    const float v = ((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3])) + bl;
+                    if (p < Bp) out[p] = v;
                 }
-                // rows(k+2) have landed once only the DMAs of the last D-2 phases are in flight (wave 0 also has one store per
-                // phase in its queue from phase 4 on)
-                if (!fetch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (w != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NA) : "memory");
-                else if (k >= D + 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (NA + 1)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                slotA = slotA == NU - 1 ? 0 : slotA + 1;
-                islotA = islotA == L::IDS_SLOTS - 1 ? 0 : islotA + 1;
+            };
+            // ReLU + bf16 of half an accumulator tile -> one ready-made layer-2 B fragment of H1 half `half`
+            auto pack_frag = [&](const f32x16 (&ac)[2], int half, int f) {
+                if (NCF_WS8_ABLATE == 8) return;
+                const int nt = f >> 1, s2 = f & 1;
+                if (NCF_WS8_ABLATE == 9) { const bf16x8_t v = pack_relu8_int(ac[nt], 8 * s2); asm volatile("" ::"v"(v)); return; }
+                if (NCF_WS8_ABLATE == 10) {
+                    const u32x4 raw = {__float_as_uint(ac[nt][8 * s2]), __float_as_uint(ac[nt][8 * s2 + 1]), __float_as_uint(ac[nt][8 * s2 + 2]), __float_as_uint(ac[nt][8 * s2 + 3])};
+                    *reinterpret_cast<u32x4*>(hwr + half * L::H1_HALF + (2 * nt + s2) * 1024) = raw;
+                    return;
+                }
+                *reinterpret_cast<bf16x8_t*>(hwr + half * L::H1_HALF + (2 * nt + s2) * 1024) = pack_relu8_int(ac[nt], 8 * s2);
+            };
+            int slot = 0, slotA = D % NU, islotA = D % L::IDS_SLOTS;
+            auto phase = [&](int k, auto pk_tag) {
+                constexpr int PK = decltype(pk_tag)::value;
+                const int nslot = slot == NU - 1 ? 0 : slot + 1;
+                const unsigned xb = slot * L::UB, xbn = nslot * L::UB;
+                W8_STAMP(0);
+#pragma unroll
+                for (int s = 0; s < Q1; ++s) {
+                    const int j = s + AHEAD;
+                    fr[j % RING] = j < Q1 ? *xp(xb, j) : *xp(xbn, j - Q1);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        if (NCF_WS8_ABLATE != 11) acc[PK][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa1[nt][s]), as_bf16x8(fr[s % RING]), acc[PK][nt], 0, 0, 0);
+                        else asm volatile("" ::"v"(fr[s % RING]));
+                    // fillers: the previous unit's accumulators -> H1, then their bias for the next unit; outputs of unit k-4
+                    if (at(s, Q1, 1, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 0);
+                    if (at(s, Q1, 2, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 1);
+                    if (at(s, Q1, 3, 8)) { if (k >= 4) store_out(k - 4); }
+                    if (at(s, Q1, 4, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 2);
+                    if (at(s, Q1, 5, 8)) pack_frag(acc[PK ^ 1], PK ^ 1, 3);
+                    if (at(s, Q1, 6, 8)) acc[PK ^ 1][0] = bias_tile(L::OFF_B1, 64 * g);
+                    if (at(s, Q1, 7, 8)) acc[PK ^ 1][1] = bias_tile(L::OFF_B1, 64 * g + 32);
+                }
+                // A's share of the gather, in the time it would otherwise spend waiting for the B waves at the barrier: the row
+                // pieces cu >= NCU - NA of unit k+D (an LDS-DMA of random rows holds its wave ~150-200 cycles)
+                if (NA > 0) {
+                    const bool fetch = k + D < n;
+                    if (fetch) {
+                        RowSrc src;
+                        locate(src, k + D, islotA);
+                        issue_rows(src, slotA, NCU - NA, NCU);
+                    }
+                    // rows(k+2) have landed once only the DMAs of the last D-2 phases are in flight (wave 0 also has one store per
+                    // phase in its queue from phase 4 on)
+                    if (!fetch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (w != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NA) : "memory");
+                    else if (k >= D + 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (NA + 1)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    slotA = slotA == NU - 1 ? 0 : slotA + 1;
+                    islotA = islotA == L::IDS_SLOTS - 1 ? 0 : islotA + 1;
+                }
+                wg_barrier();
+                slot = nslot;
+            };
+            int k = 0;
+            for (; k + 1 < n; k += 2) {
+                phase(k, std::integral_constant<int, 0>{});
+                phase(k + 1, std::integral_constant<int, 1>{});
             }
-            wg_barrier();
-            slot = nslot;
-        };
-        int k = 0;
-        for (; k + 1 < n; k += 2) {
-            phase(k, std::integral_constant<int, 0>{});
-            phase(k + 1, std::integral_constant<int, 1>{});
-        }
-        if (k < n) { phase(k, std::integral_constant<int, 0>{}); ++k; }
-        // drain: phase n packs the last unit; phases n .. n+3 store the last four units' outputs
-        if (n & 1) {
+            if (k < n) { phase(k, std::integral_constant<int, 0>{}); ++k; }
+            // drain: phase n packs the last unit; phases n .. n+3 store the last four units' outputs
+            if (n & 1) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) pack_frag(acc[0], 0, f);
-        } else {
+                for (int f = 0; f < 4; ++f) pack_frag(acc[0], 0, f);
+            } else {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) pack_frag(acc[1], 1, f);
-        }
+                for (int f = 0; f < 4; ++f) pack_frag(acc[1], 1, f);
+            }
 #pragma unroll
-        for (int dph = 0; dph < 4; ++dph) {
-            if (n + dph >= 4) store_out(n + dph - 4);
-            if (dph < 3) wg_barrier();
+            for (int dph = 0; dph < 4; ++dph) {
+                if (n + dph >= 4) store_out(n + dph - 4);
+                if (dph < 3) wg_barrier();
+            }
         }
     } else {
         // ============================================ B: layer 2, last layer, I/O ============================================
@@ -357,109 +479,219 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        u32x4 wa2[Q2];
+        if constexpr (M16) {
+            // ---- 16x16x32 form: 2 row tiles x 2 column tiles; a unit's 2 KS2 H1 fragments feed 2 MFMAs each ----
+            constexpr int KS2 = N1 / 32, NF = 2 * KS2;
+            const int p16 = lane & 15, kg = lane >> 4;
+            u32x4 wb[2][KS2];
 #pragma unroll
-        for (int q = 0; q < Q2; ++q)
-            wa2[q] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp2) + ((size_t)(q * (N2 / 32) + g) * 64 + lane) * 16);
+            for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
-        for (int q = 0; q < Q2; ++q) asm volatile("" ::"v"(wa2[q]));
-        if (!NCF_WS8_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wg_barrier();
+                for (int rt = 0; rt < 2; ++rt)
+                    wb[rt][ks] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp2m) + ((size_t)(ks * (N2 / 16) + 2 * g + rt) * 64 + lane) * 16);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) asm volatile("" ::"v"(wb[0][ks]), "v"(wb[1][ks]));
+            if (!NCF_WS8_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wg_barrier();
 
-        const unsigned char* const hbase = lds + L::OFF_H1 + lane * 16;
-        const unsigned char* const wlp = lds + L::OFF_WL + (32 * g + 4 * h) * 4;
-        f32x16 acc2[2];
-        acc2[0] = bias_tile(L::OFF_B2, 32 * g);
-        acc2[1] = acc2[0];
-        auto l2_stream = [&](f32x16& acc, int half, auto&& fill) {
-            constexpr int RB = NCF_WS8_RINGB, AB = RB - 1;
-            u32x4 fr[RB];
+            const unsigned char* const hbase = lds + L::OFF_H1 + lane * 16;
+            const unsigned char* const b2p = lds + L::OFF_B2 + (32 * g + 4 * kg) * 4;
+            f32x4 wlr[2];                                    // the last layer's weights of this lane's 8 neurons (32g + 16 rt + 4 kg + r)
 #pragma unroll
-            for (int j = 0; j < AB; ++j) fr[j] = *reinterpret_cast<const u32x4*>(hbase + half * L::H1_HALF + j * 1024);
+            for (int rt = 0; rt < 2; ++rt) wlr[rt] = *reinterpret_cast<const f32x4*>(lds + L::OFF_WL + (32 * g + 16 * rt + 4 * kg) * 4);
+            f32x4 acc2[2][2][2];                             // [unit parity][row tile][column tile]
+            auto bias_init = [&](f32x4 (&ac)[2][2]) {
 #pragma unroll
-            for (int q = 0; q < Q2; ++q) {
-                if (q + AB < Q2) fr[(q + AB) % RB] = *reinterpret_cast<const u32x4*>(hbase + half * L::H1_HALF + (q + AB) * 1024);
-                if (NCF_WS8_ABLATE != 7 && NCF_WS8_ABLATE != 11) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa2[q]), as_bf16x8(fr[q % RB]), acc, 0, 0, 0);
-                else asm volatile("" ::"v"(fr[q % RB]));
-                fill(q);
-            }
-        };
-        auto dot_quarter = [&](const f32x16& acc, int gq, float part) {
-            const f32x4 ww = *reinterpret_cast<const f32x4*>(wlp + 32 * gq);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) part = fmaf(ww[jj], relu1(acc[4 * gq + jj]), part);
-            return part;
-        };
-        auto publish = [&](int par, float part) { red[((par * 32 + m) * 4 + g) * 2 + h] = part; };
-        int slot = (NCF_WS8_STAGE ? 2 : D) % NU, islot = D % L::IDS_SLOTS, islot2 = (2 * D) % L::IDS_SLOTS;   // of units k+D (rows, ids read) and k+2D (ids written)
-        auto phase = [&](int k, auto pk_tag) {
-            constexpr int PK = decltype(pk_tag)::value;      // parity of k: layer 2 of unit k-2 -> acc2[PK], dot of unit k-3 from acc2[PK^1]
-            const bool fetch = k + D < n && NCF_WS8_ABLATE != 6;
-            float part = 0.f;
-            W8_STAMP(0);
-            RowSrc src;
-            l2_stream(acc2[PK], PK, [&](int q) {
-                if (NCF_WS8_STAGE) {
-                    if (q == 0) {
-                        store_rows(rowbuf[PK], slot);        // unit k+2 (slot of unit k+D with D = 3 ... one behind: see below)
-                        const Ids cur = idsbuf[PK];          // ids of unit k+4
-                        load_ids(idsbuf[PK], k + 6);
-                        load_rows(rowbuf[PK], cur, k + 4);
-                    }
-                } else
-                // the DMAs are spread over the stream: an LDS-DMA of gathered rows holds the wave ~100-200 cycles, during which the
-                // MFMAs it issued just before keep the matrix pipe busy
-                if (NCF_WS8_SPREAD) {
-                    if (q == 0 && fetch) { locate(src, k + D, islot); ids_dma(k + 2 * D, islot2); }
-                    if (q >= 1 && (q - 1) % NCF_WS8_SPREAD == 0 && (q - 1) / NCF_WS8_SPREAD < NCU - NA && fetch) issue_row(src, slot, (q - 1) / NCF_WS8_SPREAD);
-                } else if (q == 0 && fetch) {
-                    locate(src, k + D, islot);
-                    ids_dma(k + 2 * D, islot2);
-                    issue_rows(src, slot, 0, NCU - NA);
+                for (int rt = 0; rt < 2; ++rt) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b2p + 64 * rt);
+                    ac[rt][0] = bb; ac[rt][1] = bb;
                 }
-                if (q == 0) W8_STAMP(4);
-                if (q == 8) W8_STAMP(5);
-                if (q % 4 == 1 && NCF_WS8_ABLATE != 5) part = dot_quarter(acc2[PK ^ 1], q / 4, part);
-                if (q == 14 && NCF_WS8_ABLATE != 5) publish(PK ^ 1, part);
-                if (q == 15) acc2[PK ^ 1] = bias_tile(L::OFF_B2, 32 * g);
-            });
-            W8_STAMP(1);
-            // rows(k+2) have landed once only the DMAs of the last D-2 phases are in flight
-            if (NCF_WS8_STAGE) { }
-            else if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (NCU - NA + 1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            W8_STAMP(2);
-            wg_barrier();
-            W8_STAMP(3);
-            slot = slot == NU - 1 ? 0 : slot + 1;
-            islot = islot == L::IDS_SLOTS - 1 ? 0 : islot + 1;
-            islot2 = islot2 == L::IDS_SLOTS - 1 ? 0 : islot2 + 1;
-        };
-        int k = 0;
-        for (; k + 1 < n; k += 2) {
-            phase(k, std::integral_constant<int, 0>{});
-            phase(k + 1, std::integral_constant<int, 1>{});
-        }
-        if (k < n) { phase(k, std::integral_constant<int, 0>{}); ++k; }
-        // drain: phase n: layer 2 of unit n-2, dot of unit n-3; phase n+1: layer 2 of n-1, dot of n-2; phase n+2: dot of n-1
-        auto drain = [&](auto pk_tag, bool l2) {
-            constexpr int PK = decltype(pk_tag)::value;
-            if (l2) l2_stream(acc2[PK], PK, [&](int) {});
-            float part = 0.f;
+            };
+            bias_init(acc2[0]); bias_init(acc2[1]);
+            auto l2_stream = [&](f32x4 (&ac)[2][2], int half, auto&& fill) {
+                constexpr int RB = NCF_WS8_RINGB, AB = RB - 1;
+                u32x4 fr[RB];
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) part = dot_quarter(acc2[PK ^ 1], gq, part);
-            publish(PK ^ 1, part);
-            acc2[PK ^ 1] = bias_tile(L::OFF_B2, 32 * g);
-            wg_barrier();
-        };
-        if (n & 1) {
-            drain(std::integral_constant<int, 1>{}, true);
-            drain(std::integral_constant<int, 0>{}, true);
-            drain(std::integral_constant<int, 1>{}, false);
+                for (int j = 0; j < AB; ++j) fr[j] = *reinterpret_cast<const u32x4*>(hbase + half * L::H1_HALF + j * 1024);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    if (j + AB < NF) fr[(j + AB) % RB] = *reinterpret_cast<const u32x4*>(hbase + half * L::H1_HALF + (j + AB) * 1024);
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        ac[rt][j / KS2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wb[rt][j % KS2]), as_bf16x8(fr[j % RB]), ac[rt][j / KS2], 0, 0, 0);
+                    fill(j);
+                }
+            };
+            auto dot_ct = [&](const f32x4 (&ac)[2][2], int ct) {
+                float part = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part = fmaf(wlr[rt][r], relu1(ac[rt][ct][r]), part);
+                return part;
+            };
+            auto publish = [&](int par, int ct, float part) { red[((par * 32 + 16 * ct + p16) * 4 + g) * 4 + kg] = part; };
+            int slot = (NCF_WS8_STAGE ? 2 : D) % NU, islot = D % L::IDS_SLOTS, islot2 = (2 * D) % L::IDS_SLOTS;
+            auto phase = [&](int k, auto pk_tag) {
+                constexpr int PK = decltype(pk_tag)::value;  // parity of k: layer 2 of unit k-2 -> acc2[PK], dot of unit k-3 from acc2[PK^1]
+                const bool fetch = k + D < n && NCF_WS8_ABLATE != 6;
+                RowSrc src;
+                l2_stream(acc2[PK], PK, [&](int q) {
+                    if (NCF_WS8_STAGE) {
+                        if (q == 0) {
+                            store_rows(rowbuf[PK], slot);
+                            const Ids cur = idsbuf[PK];
+                            load_ids(idsbuf[PK], k + 6);
+                            load_rows(rowbuf[PK], cur, k + 4);
+                        }
+                    } else if (NCF_WS8_SPREAD) {
+                        if (q == 0 && fetch) { locate(src, k + D, islot); ids_dma(k + 2 * D, islot2); }
+                        if (q >= 1 && (q - 1) % NCF_WS8_SPREAD == 0 && (q - 1) / NCF_WS8_SPREAD < NCU - NA && fetch) issue_row(src, slot, (q - 1) / NCF_WS8_SPREAD);
+                    } else if (q == 0 && fetch) {
+                        locate(src, k + D, islot);
+                        ids_dma(k + 2 * D, islot2);
+                        issue_rows(src, slot, 0, NCU - NA);
+                    }
+                    if (q == 5) publish(PK ^ 1, 0, dot_ct(acc2[PK ^ 1], 0));
+                    if (q == 11) publish(PK ^ 1, 1, dot_ct(acc2[PK ^ 1], 1));
+                    if (q == 14) bias_init(acc2[PK ^ 1]);
+                });
+                if (NCF_WS8_STAGE) { }
+                else if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (NCU - NA + 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wg_barrier();
+                slot = slot == NU - 1 ? 0 : slot + 1;
+                islot = islot == L::IDS_SLOTS - 1 ? 0 : islot + 1;
+                islot2 = islot2 == L::IDS_SLOTS - 1 ? 0 : islot2 + 1;
+            };
+            int k = 0;
+            for (; k + 1 < n; k += 2) {
+                phase(k, std::integral_constant<int, 0>{});
+                phase(k + 1, std::integral_constant<int, 1>{});
+            }
+            if (k < n) { phase(k, std::integral_constant<int, 0>{}); ++k; }
+            auto drain = [&](auto pk_tag, bool l2) {
+                constexpr int PK = decltype(pk_tag)::value;
+                if (l2) l2_stream(acc2[PK], PK, [&](int) {});
+                publish(PK ^ 1, 0, dot_ct(acc2[PK ^ 1], 0));
+                publish(PK ^ 1, 1, dot_ct(acc2[PK ^ 1], 1));
+                bias_init(acc2[PK ^ 1]);
+                wg_barrier();
+            };
+            if (n & 1) {
+                drain(std::integral_constant<int, 1>{}, true);
+                drain(std::integral_constant<int, 0>{}, true);
+                drain(std::integral_constant<int, 1>{}, false);
+            } else {
+                drain(std::integral_constant<int, 0>{}, true);
+                drain(std::integral_constant<int, 1>{}, true);
+                drain(std::integral_constant<int, 0>{}, false);
+            }
         } else {
-            drain(std::integral_constant<int, 0>{}, true);
-            drain(std::integral_constant<int, 1>{}, true);
-            drain(std::integral_constant<int, 0>{}, false);
+            u32x4 wa2[Q2];
+#pragma unroll
+            for (int q = 0; q < Q2; ++q)
+                wa2[q] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp2) + ((size_t)(q * (N2 / 32) + g) * 64 + lane) * 16);
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) asm volatile("" ::"v"(wa2[q]));
+            if (!NCF_WS8_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wg_barrier();
+
+            const unsigned char* const hbase = lds + L::OFF_H1 + lane * 16;
+            const unsigned char* const wlp = lds + L::OFF_WL + (32 * g + 4 * h) * 4;
+            f32x16 acc2[2];
+            acc2[0] = bias_tile(L::OFF_B2, 32 * g);
+            acc2[1] = acc2[0];
+            auto l2_stream = [&](f32x16& acc, int half, auto&& fill) {
+                constexpr int RB = NCF_WS8_RINGB, AB = RB - 1;
+                u32x4 fr[RB];
+#pragma unroll
+                for (int j = 0; j < AB; ++j) fr[j] = *reinterpret_cast<const u32x4*>(hbase + half * L::H1_HALF + j * 1024);
+#pragma unroll
+                for (int q = 0; q < Q2; ++q) {
+                    if (q + AB < Q2) fr[(q + AB) % RB] = *reinterpret_cast<const u32x4*>(hbase + half * L::H1_HALF + (q + AB) * 1024);
+                    if (NCF_WS8_ABLATE != 7 && NCF_WS8_ABLATE != 11) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wa2[q]), as_bf16x8(fr[q % RB]), acc, 0, 0, 0);
+                    else asm volatile("" ::"v"(fr[q % RB]));
+                    fill(q);
+                }
+            };
+            auto dot_quarter = [&](const f32x16& acc, int gq, float part) {
+                const f32x4 ww = *reinterpret_cast<const f32x4*>(wlp + 32 * gq);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) part = fmaf(ww[jj], relu1(acc[4 * gq + jj]), part);
+                return part;
+            };
+            auto publish = [&](int par, float part) { red[((par * 32 + m) * 4 + g) * 2 + h] = part; };
+            int slot = (NCF_WS8_STAGE ? 2 : D) % NU, islot = D % L::IDS_SLOTS, islot2 = (2 * D) % L::IDS_SLOTS;   // of units k+D (rows, ids read) and k+2D (ids written)
+            auto phase = [&](int k, auto pk_tag) {
+                constexpr int PK = decltype(pk_tag)::value;      // parity of k: layer 2 of unit k-2 -> acc2[PK], dot of unit k-3 from acc2[PK^1]
+                const bool fetch = k + D < n && NCF_WS8_ABLATE != 6;
+                float part = 0.f;
+                W8_STAMP(0);
+                RowSrc src;
+                l2_stream(acc2[PK], PK, [&](int q) {
+                    if (NCF_WS8_STAGE) {
+                        if (q == 0) {
+                            store_rows(rowbuf[PK], slot);        // unit k+2 (slot of unit k+D with D = 3 ... one behind: see below)
+                            const Ids cur = idsbuf[PK];          // ids of unit k+4
+                            load_ids(idsbuf[PK], k + 6);
+                            load_rows(rowbuf[PK], cur, k + 4);
+                        }
+                    } else
+                    // the DMAs are spread over the stream: an LDS-DMA of gathered rows holds the wave ~100-200 cycles, during which the
+                    // MFMAs it issued just before keep the matrix pipe busy
+                    if (NCF_WS8_SPREAD) {
+                        if (q == 0 && fetch) { locate(src, k + D, islot); ids_dma(k + 2 * D, islot2); }
+                        if (q >= 1 && (q - 1) % NCF_WS8_SPREAD == 0 && (q - 1) / NCF_WS8_SPREAD < NCU - NA && fetch) issue_row(src, slot, (q - 1) / NCF_WS8_SPREAD);
+                    } else if (q == 0 && fetch) {
+                        locate(src, k + D, islot);
+                        ids_dma(k + 2 * D, islot2);
+                        issue_rows(src, slot, 0, NCU - NA);
+                    }
+                    if (q == 0) W8_STAMP(4);
+                    if (q == 8) W8_STAMP(5);
+                    if (q % 4 == 1 && NCF_WS8_ABLATE != 5) part = dot_quarter(acc2[PK ^ 1], q / 4, part);
+                    if (q == 14 && NCF_WS8_ABLATE != 5) publish(PK ^ 1, part);
+                    if (q == 15) acc2[PK ^ 1] = bias_tile(L::OFF_B2, 32 * g);
+                });
+                W8_STAMP(1);
+                // rows(k+2) have landed once only the DMAs of the last D-2 phases are in flight
+                if (NCF_WS8_STAGE) { }
+                else if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (NCU - NA + 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                W8_STAMP(2);
+                wg_barrier();
+                W8_STAMP(3);
+                slot = slot == NU - 1 ? 0 : slot + 1;
+                islot = islot == L::IDS_SLOTS - 1 ? 0 : islot + 1;
+                islot2 = islot2 == L::IDS_SLOTS - 1 ? 0 : islot2 + 1;
+            };
+            int k = 0;
+            for (; k + 1 < n; k += 2) {
+                phase(k, std::integral_constant<int, 0>{});
+                phase(k + 1, std::integral_constant<int, 1>{});
+            }
+            if (k < n) { phase(k, std::integral_constant<int, 0>{}); ++k; }
+            // drain: phase n: layer 2 of unit n-2, dot of unit n-3; phase n+1: layer 2 of n-1, dot of n-2; phase n+2: dot of n-1
+            auto drain = [&](auto pk_tag, bool l2) {
+                constexpr int PK = decltype(pk_tag)::value;
+                if (l2) l2_stream(acc2[PK], PK, [&](int) {});
+                float part = 0.f;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) part = dot_quarter(acc2[PK ^ 1], gq, part);
+                publish(PK ^ 1, part);
+                acc2[PK ^ 1] = bias_tile(L::OFF_B2, 32 * g);
+                wg_barrier();
+            };
+            if (n & 1) {
+                drain(std::integral_constant<int, 1>{}, true);
+                drain(std::integral_constant<int, 0>{}, true);
+                drain(std::integral_constant<int, 1>{}, false);
+            } else {
+                drain(std::integral_constant<int, 0>{}, true);
+                drain(std::integral_constant<int, 1>{}, true);
+                drain(std::integral_constant<int, 0>{}, false);
+            }
         }
         if (oob_seen && a.oob) *a.oob = 1;
     }
@@ -476,10 +708,11 @@ bool ws8_shape_ok(int K0, int N1, int N2) { return (K0 == 256 || K0 == 128) && N
 void launch_ws8_bf16(int K0, const Bf16Args& a, const unsigned char* zeros, hipStream_t s) {
     const int nunits = (int)((a.B + 31) / 32);
     const int grid = nunits < num_cus() ? nunits : num_cus();
+    constexpr bool M16 = NCF_WS8_M16 != 0;
     if (K0 == 256)
-        hipLaunchKernelGGL((score_ws8_bf16_kernel<256>), dim3((unsigned)grid), dim3(512), 0, s, a, a.idxA, a.idxB, a.out, zeros, nunits);
+        hipLaunchKernelGGL((score_ws8_bf16_kernel<256, M16>), dim3((unsigned)grid), dim3(512), 0, s, a, a.idxA, a.idxB, a.out, zeros, nunits);
     else
-        hipLaunchKernelGGL((score_ws8_bf16_kernel<128>), dim3((unsigned)grid), dim3(512), 0, s, a, a.idxA, a.idxB, a.out, zeros, nunits);
+        hipLaunchKernelGGL((score_ws8_bf16_kernel<128, M16>), dim3((unsigned)grid), dim3(512), 0, s, a, a.idxA, a.idxB, a.out, zeros, nunits);
 }
 
 }  // namespace ncf
