@@ -445,6 +445,7 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
             for (int i = 0; i < NCU; ++i)
                 *reinterpret_cast<u32x4*>(lds + slot * L::UB + (i / NJ) * TSTRIDE + (g * NJ + i % NJ) * 1024 + lane * 16) = rb[i];
         };
+        RowSrc psrc[D];                                      // prologue only
         if (NCF_WS8_STAGE) {
             Ids i0, i1;
             u32x4 r0[NCU], r1[NCU];
@@ -454,7 +455,10 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
             load_ids(idsbuf[0], 4); load_ids(idsbuf[1], 5);
             store_rows(r0, 0); store_rows(r1, 1);
         } else {
-            // prologue: units 0..D-1 by direct id loads, ids of units D..2D-1 by DMA; then the weights (their wait drains the queue)
+            // prologue, first part: the ids of units 0..D-1 by direct loads, the rows of units 0 and 1 and the ids of units D..2D-1
+            // (phase 0 reads ids(D) at once) by DMA; then the weights.  Only once all of that has arrived (one drain of the queue)
+            // the rows of units 2..D-1 are requested: they land during the first phases (per unit they are at least as many queue
+            // entries as a steady-state phase issues, so the counted waits of the loop are at worst early).
             {
                 int64_t pid[D][NJ][2];
     #pragma unroll
@@ -468,16 +472,21 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
                     }
     #pragma unroll
                 for (int t = 0; t < D; ++t) {
-                    RowSrc s0;
     #pragma unroll
-                    for (int j = 0; j < NJ; ++j) resolve(s0, j, unit_pair0(t) + 8 * g + PP * j + dpp, pid[t][j][0], pid[t][j][1]);
-                    if (t < n) issue_rows(s0, t, 0, NCU);
+                    for (int j = 0; j < NJ; ++j) resolve(psrc[t], j, unit_pair0(t) + 8 * g + PP * j + dpp, pid[t][j][0], pid[t][j][1]);
+                    if (t < 2 && t < n) issue_rows(psrc[t], t, 0, NCU);
                 }
     #pragma unroll
-                for (int t = 0; t < D; ++t)
+                for (int t = 0; t < D; ++t)                  // phase 0 reads ids(D) at once: they belong to the drained part
                     if (D + t < n) ids_dma(D + t, (D + t) % L::IDS_SLOTS);
             }
         }
+        auto prologue_rest = [&]() {
+            if (NCF_WS8_STAGE) return;
+    #pragma unroll
+            for (int t = 2; t < D; ++t)
+                if (t < n) issue_rows(psrc[t], t, 0, NCU);
+        };
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (M16) {
             // ---- 16x16x32 form: 2 row tiles x 2 column tiles; a unit's 2 KS2 H1 fragments feed 2 MFMAs each ----
@@ -492,6 +501,7 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) asm volatile("" ::"v"(wb[0][ks]), "v"(wb[1][ks]));
             if (!NCF_WS8_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prologue_rest();
             wg_barrier();
 
             const unsigned char* const hbase = lds + L::OFF_H1 + lane * 16;
@@ -595,6 +605,7 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
 #pragma unroll
             for (int q = 0; q < Q2; ++q) asm volatile("" ::"v"(wa2[q]));
             if (!NCF_WS8_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prologue_rest();
             wg_barrier();
 
             const unsigned char* const hbase = lds + L::OFF_H1 + lane * 16;
