@@ -446,6 +446,16 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
                 *reinterpret_cast<u32x4*>(lds + slot * L::UB + (i / NJ) * TSTRIDE + (g * NJ + i % NJ) * 1024 + lane * 16) = rb[i];
         };
         RowSrc psrc[D];                                      // prologue only
+        u32x4 wb[2][N1 / 32];                                // layer-2 A fragments of the 16x16x32 form (M16)
+        auto load_wb = [&]() {                               // issued BEHIND the id loads, so that their latencies overlap
+            if constexpr (M16) {
+#pragma unroll
+                for (int ks = 0; ks < N1 / 32; ++ks)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        wb[rt][ks] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp2m) + ((size_t)(ks * (N2 / 16) + 2 * g + rt) * 64 + lane) * 16);
+            }
+        };
         if (NCF_WS8_STAGE) {
             Ids i0, i1;
             u32x4 r0[NCU], r1[NCU];
@@ -470,6 +480,7 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
                         pid[t][j][0] = idxA[p];
                         pid[t][j][1] = idxB[p];
                     }
+                load_wb();
     #pragma unroll
                 for (int t = 0; t < D; ++t) {
     #pragma unroll
@@ -492,12 +503,7 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
             // ---- 16x16x32 form: 2 row tiles x 2 column tiles; a unit's 2 KS2 H1 fragments feed 2 MFMAs each ----
             constexpr int KS2 = N1 / 32, NF = 2 * KS2;
             const int p16 = lane & 15, kg = lane >> 4;
-            u32x4 wb[2][KS2];
-#pragma unroll
-            for (int ks = 0; ks < KS2; ++ks)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-                    wb[rt][ks] = ldg16(reinterpret_cast<const unsigned char*>(a.Wp2m) + ((size_t)(ks * (N2 / 16) + 2 * g + rt) * 64 + lane) * 16);
+            if (NCF_WS8_STAGE) load_wb();
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) asm volatile("" ::"v"(wb[0][ks]), "v"(wb[1][ks]));
             if (!NCF_WS8_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
