@@ -482,7 +482,7 @@ def run_cfg5(args, ctx):
         outl = torch.empty((BL, 1), device=device)
         ktl = bench.kernel_time("ncf::score_ws8_bf16_kernel", f"cfg5_b{BL}", lambda: native.score_fused(tu, lu2, ti, li2, model.packed, out=outl), reps=30, settle=10)
         tfl = flop * BL / (ktl["us"] * 1e-6) / 1e12
-        big_variant = {"kernel": "score_ws8_bf16_kernel<256>", "us_per_launch": ktl["us"], "us_per_launch_basis": ktl["basis"],
+        big_variant = {"kernel": "score_ws8_bf16_kernel<256,true>", "us_per_launch": ktl["us"], "us_per_launch_basis": ktl["basis"],
                        "us_back_to_back": ktl["us_back_to_back"], "rocprof_avg_us": ktl["rocprof_avg_us"], "profile": ktl["profile"],
                        "pairs_per_s": BL / (ktl["us"] * 1e-6), "achieved_TFLOPs": tfl, "frac_of_bf16_mfma_peak": tfl / bench.PEAK_BF16_MFMA_TFLOPS,
                        "hbm_GBps_at_this_rate": 532 * BL / (ktl["us"] * 1e-6) / 1e9}
@@ -498,7 +498,7 @@ def run_cfg5(args, ctx):
                                    "device-side owner bucketing into fixed-capacity buffers, equal-split all-to-alls, step t+1's exchange "
                                    "on a second stream under step t's MLP; value = the fastest form below"},
             "exchange_forms": forms,
-            "roofline": {"kernel": "score_ws8_bf16_kernel<256>", "bound": "mfma", "achieved": tf, "peak": bench.PEAK_BF16_MFMA_TFLOPS,
+            "roofline": {"kernel": "score_ws8_bf16_kernel<256,true>", "bound": "mfma", "achieved": tf, "peak": bench.PEAK_BF16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": tf / bench.PEAK_BF16_MFMA_TFLOPS, "traffic": kt["traffic"], "us_per_launch": us,
                          "us_per_launch_basis": kt["basis"], "us_back_to_back": us_b2b, "us_isolated_events": kt["us_isolated_events"],
                          "algorithmic_flop_per_pair": flop, "algorithmic_bytes_per_pair": 532,

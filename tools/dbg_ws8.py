@@ -1,3 +1,4 @@
+"""Dev tool (GPU box): which outputs of the 8-wave bf16 kernel differ from the 4-wave kernel's, by unit and position (pipeline debugging)."""
 import sys, torch
 sys.path.insert(0, '/root/repo')
 from deeprecommendation_amd import native
