@@ -118,6 +118,11 @@ def profile_digest(kernel_prefix, context):
     for name, k in d.get("kernels", {}).items():
         if name.startswith(kernel_prefix):
             out = {"rocprof_avg_us": k.get("rocprof_avg_us"), "profile": os.path.basename(path)}
+            if k.get("gui_active_cycles_sum8xcd") and k.get("rocprof_avg_us"):
+                # GRBM_GUI_ACTIVE sums the 8 XCDs; the quotient is the clock the chip held (reads high on launches under ~0.2 ms)
+                out["held_clock_GHz"] = k["gui_active_cycles_sum8xcd"] / 8 / k["rocprof_avg_us"] / 1e3
+                if k.get("mfma_busy_cycles"):
+                    out["mfma_busy_frac_of_held_cycles"] = k["mfma_busy_cycles"] / 1024 / (k["gui_active_cycles_sum8xcd"] / 8)
             if "fetch_bytes" in k or "write_bytes" in k:
                 out["traffic"] = k.get("fetch_bytes", 0.0) + k.get("write_bytes", 0.0)
                 out["fetch_bytes"], out["write_bytes"] = k.get("fetch_bytes"), k.get("write_bytes")
