@@ -153,7 +153,8 @@ __global__ __launch_bounds__(KS > 4 ? KS * 64 : 256) void linear_rs_kernel(const
                                                         int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
                                                         int64_t ldc, int64_t M, int K) {
     constexpr int WAVES = KS > 4 ? KS : 4;   // KS = 8 / 16: one tile per 512- / 1024-thread workgroup
-    __shared__ __attribute__((aligned(16))) float red[KS > 1 ? WAVES * NT * 16 * 64 : 4];
+    // KS >= 8: the same array first stages each wave's A / W blocks (2 x 32 x 32 floats per wave), then carries the partial sums
+    __shared__ __attribute__((aligned(16))) float red[KS >= 8 ? WAVES * 2048 : (KS > 1 ? WAVES * NT * 16 * 64 : 4)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * (WAVES / KS) + wave / KS;
@@ -176,8 +177,68 @@ __global__ __launch_bounds__(KS > 4 ? KS * 64 : 256) void linear_rs_kernel(const
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
     const int Q = K / 8;
-    const int qlo = (int)((int64_t)ks * Q / KS), qhi = (int)((int64_t)(ks + 1) * Q / KS);
+    // KS >= 8 (skinny and deep): the whole 32-wide blocks of K go through the staged loop below, split over the waves; what is
+    // left of K (< 32) is the last wave's, on the direct path
+    const int qlo = KS >= 8 ? (ks == KS - 1 ? 4 * (K / 32) : 0) : (int)((int64_t)ks * Q / KS);
+    const int qhi = KS >= 8 ? (ks == KS - 1 ? Q : 0) : (int)((int64_t)(ks + 1) * Q / KS);
     if (tile_ok) {
+      if constexpr (KS >= 8) {
+        // Staged form.  Read straight into MFMA operand layout (lane = row), a 16-byte load per lane touches 32 rows: 32 pieces of
+        // 32 bytes per instruction, and at K = 2094 the CU's address path, not HBM or the MFMAs, set the time (4096 x 2094 -> 64:
+        // 30 us for 34 MB and 1.1 GFLOP).  Here a wave loads its 32 x 32 block of A and of W with eight consecutive lanes per row
+        // (whole 128-byte runs: 8 lines per instruction instead of 32 pieces), parks them in its own 8 KB of LDS (16-byte slot s
+        // of row r at s ^ ((r >> 1) & 7): conflict-free ds_write_b128 and operand-layout ds_read_b128) and reads them back as
+        // operands.  No barrier: a wave reads only what it wrote, and a wave's LDS instructions execute in order.  Same k pairing
+        // per MFMA as the direct path (k = 8q + 4h + j).
+        static_assert(NT == 1, "the staged split-K form keeps one column tile per workgroup");
+        float* const stA = red + (size_t)wave * 2048;
+        float* const stW = stA + 1024;
+        const int NB = K / 32;
+        const int blo = (int)((int64_t)ks * NB / KS), bhi = (int)((int64_t)(ks + 1) * NB / KS);
+        const int lr = lane >> 3, ls = lane & 7;
+        const float* ga[4];
+        const float* gw[4];
+        unsigned wo[4], ro[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int r = 8 * c + lr;
+            const int64_t mm = tile * 32 + r;
+            ga[c] = A + (mm < M ? mm : (M - 1)) * lda + 4 * ls;
+            gw[c] = W + (int64_t)r * ldw + 4 * ls;
+            wo[c] = r * 32 + ((ls ^ ((r >> 1) & 7)) << 2);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ro[q] = i * 32 + ((((2 * q + h) ^ ((i >> 1) & 7)) & 7) << 2);
+        // one block ahead in registers (two ahead measured no better: 22.6 vs 21.6 us at 4096 x 2094 -> 64)
+        f32x4 va[4], vw[4];
+        if (bhi > blo) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                va[c] = *reinterpret_cast<const f32x4u*>(ga[c] + 32 * blo);
+                vw[c] = *reinterpret_cast<const f32x4u*>(gw[c] + 32 * blo);
+            }
+        }
+        for (int b = blo; b < bhi; ++b) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                *reinterpret_cast<f32x4*>(stA + wo[c]) = va[c];
+                *reinterpret_cast<f32x4*>(stW + wo[c]) = vw[c];
+            }
+            const int bn = b + 1 < bhi ? b + 1 : b;         // the last iteration fetches its own block again (harmless, no branch)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                va[c] = *reinterpret_cast<const f32x4u*>(ga[c] + 32 * bn);
+                vw[c] = *reinterpret_cast<const f32x4u*>(gw[c] + 32 * bn);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(stA + ro[q]);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(stW + ro[q]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w[j], acc[0], 0, 0, 0);
+            }
+        }
+      }
       if (qhi > qlo) {
         // A fragments run PD k-steps ahead of the MFMAs in a register ring: the A rows stream from HBM, and with the
         // one-step-ahead pipeline this kernel had, a CU kept 8 KB in flight — 2 MB chip-wide, i.e. 1.9 TB/s at ~1 us of
@@ -237,6 +298,7 @@ __global__ __launch_bounds__(KS > 4 ? KS * 64 : 256) void linear_rs_kernel(const
         }
     }
     if (KS > 1) {
+        if constexpr (KS >= 8) __syncthreads();             // every wave is done with its staging area (the sums reuse the array)
         float* mine = red + (size_t)wave * (NT * 16 * 64);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -411,7 +473,9 @@ static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ld
             // 4096 x 2094 -> 64: 36.5 -> 29.9 us, 2048 rows 27.1 -> 26.0; NOT beyond 256 workgroups (8192 rows: 48.8 -> 61.0,
             // N = 128: 47.2 -> 55.5) and 16 slices lose everywhere (tools/ab_linear_env.py, ncf_set_option("linear_kslices", 4|8) forces one)
             const int ksf = option(NCF_OPT_LINEAR_KSLICES);
-            const bool ks8 = ksf ? ksf == 8 : (tiles * NT <= 256 && K >= 1024);
+            // (staged A / W blocks since round 2: 4096 x 2094 -> 64 21.6 us vs 36.4 on 4 slices, 8192 rows 41.1 vs 48.1, N = 128 38.5 vs
+            // 46.4, 4096 x 1030 -> 64 13.4 vs 18.1: tools/ab_skinny_linear.py)
+            const bool ks8 = ksf ? ksf == 8 : K >= 1024;
             if (ks8) return launch_rs<1, 8>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s, NT);
             return launch_rs<1, 4>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s, NT);
         }
