@@ -447,6 +447,43 @@ def run_cfg5(args, ctx):
     forms["bounded_pipelined" if world > 1 else "single_gpu"] = {"ms_per_step": wall / args.steps * 1e3, "pairs_per_s": world * B * args.steps / wall,
                                                                   "capacity": caps, "overflow": overflow}
     main_wall, main_warm = wall, warm
+    step_form = "one launch per step from Python"
+    if world == 1:
+        # The step is ONE ~16 us kernel, about what Python + ctypes need to enqueue it: the same steps captured in a HIP graph
+        # (the 8 resident batches in order, no copies: one graph launch = 8 steps) take the host out of the loop.
+        try:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                for k in range(nb):
+                    model(*batches[k])
+            torch.cuda.current_stream(device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gouts = [model(*batches[k]) for k in range(nb)]
+            graph.replay()
+            torch.cuda.synchronize()
+            for k in (0, nb - 1):
+                if not torch.equal(gouts[k], model(*batches[k])):
+                    raise RuntimeError("graph replay differs from the eager step")
+            full = (args.steps // nb) * nb
+
+            def gstep(j):                      # steps 0 .. full-1 in graph launches of nb steps, the remainder one by one
+                if j < full:
+                    if j % nb == 0:
+                        graph.replay()
+                else:
+                    model(*batches[j % nb])
+            wall_g, _ = _time_steps(gstep, args.warmup, args.steps, ctx)
+            wall_g = ctx.max_over_ranks(wall_g)
+            forms["single_gpu_graph"] = {"ms_per_step": wall_g / args.steps * 1e3, "pairs_per_s": B * args.steps / wall_g,
+                                         "steps_per_graph_launch": nb}
+            if wall_g < main_wall:
+                main_wall = wall_g
+                step_form = f"HIP graph of {nb} steps (the resident batches in order, no copies) per launch"
+            del graph, gouts
+        except Exception as exc:  # noqa: BLE001
+            forms["single_gpu_graph"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world > 1:
         for name, kw, pipe in (("bounded_serial", {"exchange": "bounded"}, False), ("unique_dedup_host_sizes", {"exchange": "unique"}, False)):
             try:
@@ -501,6 +538,7 @@ def run_cfg5(args, ctx):
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"cfg5: BasicNCF {U} users x {I} items, emb_dim={E} bf16, local batch {B}, MLP 256-256-128-1, "
                                    f"user table row-sharded x{world}, item table {'replicated' if replicate else 'row-sharded'}",
+                       "step": step_form,
                        "exchange": "none (both tables on the one GPU)" if world == 1 else
                                    "device-side owner bucketing into fixed-capacity buffers, equal-split all-to-alls, step t+1's exchange "
                                    "on a second stream under step t's MLP; value = the fastest form below"},
