@@ -20,6 +20,9 @@ ti = (torch.randn(I, E, device=dev, generator=g) * 0.05).to(torch.bfloat16)
 dims = [256, 256, 128, 1]
 ws = [torch.randn(dims[i + 1], dims[i], device=dev, generator=g) / dims[i] ** 0.5 for i in range(3)]
 bs = [torch.randn(dims[i + 1], device=dev, generator=g) * 0.1 for i in range(3)]
+if os.environ.get("AB_ZERO") == "1":      # all-zero operands: same instruction stream and ids, far less switching power
+    tu.zero_(); ti.zero_()
+    ws = [w * 0 for w in ws]
 packed = native.PackedMLP(ws, bs, dtype=torch.bfloat16)
 iu = torch.randint(0, U, (Bsz,), device=dev, generator=g)
 ii = torch.randint(0, I, (Bsz,), device=dev, generator=g)
