@@ -253,6 +253,7 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
                 constexpr int PK = decltype(pk_tag)::value;
                 const int nslot = slot == NU - 1 ? 0 : slot + 1;
                 const unsigned xb = slot * L::UB, xbn = nslot * L::UB;
+                W8_STAMP(0);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     const int jn = j + AHEAD;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
                     if (at(j, NF, 6, 8)) { bias_init(acc[PK ^ 1], 0); bias_init(acc[PK ^ 1], 1); }
                     if (at(j, NF, 7, 8)) { bias_init(acc[PK ^ 1], 2); bias_init(acc[PK ^ 1], 3); }
                 }
+                W8_STAMP(1);
                 if (NA > 0) {
                     const bool fetch = k + D < n;
                     if (fetch) {
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
                         locate(src, k + D, islotA);
                         issue_rows(src, slotA, NCU - NA, NCU);
                     }
+                    W8_STAMP(4);
                     if (!fetch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     else if (w != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NA) : "memory");
                     else if (k >= D + 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (NA + 1)) : "memory");
@@ -282,7 +285,9 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
                     slotA = slotA == NU - 1 ? 0 : slotA + 1;
                     islotA = islotA == L::IDS_SLOTS - 1 ? 0 : islotA + 1;
                 }
+                W8_STAMP(2);
                 wg_barrier();
+                W8_STAMP(3);
                 slot = nslot;
             };
             int k = 0;
@@ -552,7 +557,9 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
                 constexpr int PK = decltype(pk_tag)::value;  // parity of k: layer 2 of unit k-2 -> acc2[PK], dot of unit k-3 from acc2[PK^1]
                 const bool fetch = k + D < n && NCF_WS8_ABLATE != 6;
                 RowSrc src;
+                W8_STAMP(0);
                 l2_stream(acc2[PK], PK, [&](int q) {
+                    if (q == 6) W8_STAMP(4);
                     if (NCF_WS8_STAGE) {
                         if (q == 0) {
                             store_rows(rowbuf[PK], slot);
@@ -572,10 +579,13 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
                     if (q == 11) publish(PK ^ 1, 1, dot_ct(acc2[PK ^ 1], 1));
                     if (q == 14) bias_init(acc2[PK ^ 1]);
                 });
+                W8_STAMP(1);
                 if (NCF_WS8_STAGE) { }
                 else if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (NCU - NA + 1)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                W8_STAMP(2);
                 wg_barrier();
+                W8_STAMP(3);
                 slot = slot == NU - 1 ? 0 : slot + 1;
                 islot = islot == L::IDS_SLOTS - 1 ? 0 : islot + 1;
                 islot2 = islot2 == L::IDS_SLOTS - 1 ? 0 : islot2 + 1;

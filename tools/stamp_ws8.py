@@ -39,15 +39,13 @@ def main():
     d = dbg.view(256, 8, 8, 8).cpu().double()       # block, wave, phase 16..23, stamp
     a, b = d[:, :4], d[:, 4:]
     per = a[:, :, 1:, 0] - a[:, :, :-1, 0]
-    print(f"phase period (A waves, stamp 0 only): median {per.median().item():.0f} cycles, mean {per.mean().item():.0f}")
-    names = [("head (locate + DMAs at q = 0)", 0, 4), ("k-steps 1..8", 4, 5), ("k-steps 9..15", 5, 1), ("vmcnt wait", 1, 2), ("barrier wait", 2, 3)]
-    for nm, i0, i1 in names:
-        x = b[..., i1] - b[..., i0]
-        print(f"B {nm}: median {x.median().item():.0f}, mean {x.mean().item():.0f}")
-    x = b[:, :, 1:, 0] - b[:, :, :-1, 3]
-    print(f"B barrier exit -> next phase start: median {x.median().item():.0f}")
-    skew = b[:, :, :, 0].mean(1) - a[:, :, :, 0].mean(1)
-    print(f"B phase start - A phase start: median {skew.median().item():.0f}")
+    print(f"phase period: median {per.median().item():.0f} cycles, mean {per.mean().item():.0f}  (each stamp costs the wave ~150-200 cycles)")
+    for nm, x, i0, i1 in (("A stream (32 or 64 MFMAs + pack)", a, 0, 1), ("A locate + row DMAs", a, 1, 4), ("A vmcnt wait", a, 4, 2), ("A barrier wait", a, 2, 3),
+                          ("B head + k-steps 0..5 (locate, ids DMA, row DMAs at 1 and 4)", b, 0, 4), ("B k-steps 6..15", b, 4, 1),
+                          ("B vmcnt wait", b, 1, 2), ("B barrier wait", b, 2, 3)):
+        v = x[..., i1] - x[..., i0]
+        print(f"{nm}: median {v.median().item():.0f}, mean {v.mean().item():.0f}")
+    print(f"B phase start - A phase start: median {(b[..., 0].mean(1) - a[..., 0].mean(1)).median().item():.0f}")
 
 
 if __name__ == "__main__":
