@@ -856,7 +856,8 @@ int bf16_score(const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, i
     ws = ws && EA % 64 == 0 && EB % 64 == 0 && idxA && (EB == 0 || idxB);
     if (ws && !idxB) a.idxB = idxA;   // single table: the id DMA's table-B lanes fetch valid (unused) words
     const int N2 = n_layers == 3 ? dims[2] : 0;
-    if (ws && force != 1 && EA == EB && B < (int64_t(1) << 31) - 64 && ws8_shape_ok(dims[0], dims[1], N2)) {
+    if (ws && force != 1 && EA == EB && B < (int64_t(1) << 31) - 64 && rowsA < (int64_t(1) << 31) && rowsB < (int64_t(1) << 31) &&
+        ldA < (int64_t(1) << 30) && ldB < (int64_t(1) << 30) && ws8_shape_ok(dims[0], dims[1], N2)) {
         launch_ws8_bf16(dims[0], a, (const unsigned char*)(P + L.zeros), s);
         return check_launch("ncf_score_fused(bf16)");
     }

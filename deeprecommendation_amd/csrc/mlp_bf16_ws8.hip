@@ -144,13 +144,16 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
     const int dpp = lane / RC, dpos = lane % RC;             // DMA role: pair dpp of the piece, slot dpos of its row
     typedef const unsigned char* RowSrc[2][NJ];              // [table][piece]
     bool oob_seen = false;
+    // (row counts and row strides fit 32 bits — the launcher checks — so a row address is one v_mad_u64_u32 and the range check one
+    // unsigned compare: a negative id is a huge unsigned one)
+    const uint32_t strideA = (uint32_t)(a.ldA * 2), strideB = (uint32_t)(a.ldB * 2);
     auto resolve = [&](RowSrc& src, int j, int p0, int64_t ia, int64_t ib) {
         const int cc = dpos ^ xkey(8 * g + PP * j + dpp);
-        const bool okA = (ia >= 0) & (ia < a.rowsA);
-        const bool okB = (ib >= 0) & (ib < a.rowsB);
+        const bool okA = (uint64_t)ia < (uint64_t)a.rowsA;
+        const bool okB = (uint64_t)ib < (uint64_t)a.rowsB;
         oob_seen |= !(okA & okB) & (p0 < Bp);
-        src[0][j] = (okA ? reinterpret_cast<const unsigned char*>(a.tabA + ia * a.ldA) : zeros) + cc * 16;
-        src[1][j] = (okB ? reinterpret_cast<const unsigned char*>(a.tabB + ib * a.ldB) : zeros) + cc * 16;
+        src[0][j] = (okA ? reinterpret_cast<const unsigned char*>(a.tabA) + (uint64_t)(uint32_t)ia * strideA : zeros) + cc * 16;
+        src[1][j] = (okB ? reinterpret_cast<const unsigned char*>(a.tabB) + (uint64_t)(uint32_t)ib * strideB : zeros) + cc * 16;
     };
     auto issue_row = [&](const RowSrc& src, int slot, int i) {   // piece i of this wave: table i / NJ, pairs 8g + PP (i % NJ) ...
         const int tb = i / NJ, j = i % NJ;
