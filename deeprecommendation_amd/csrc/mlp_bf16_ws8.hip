@@ -131,9 +131,8 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
     // ---- the gather: ids and rows by LDS-DMA (helpers shared by both roles; wave g of either role serves pairs 8g .. 8g+7) ----
     // X image of a unit (EA = EB = K0/2): per table 32 / PP pieces of PP pairs x RC 16-byte chunks — every piece holds WHOLE table
     // rows, so that one DMA instruction reads PP rows, each by RC consecutive lanes (K0 = 256: 4 rows of 256 B; K0 = 128: 8 rows
-    // of 128 B).  The memory path of a CU takes one random row (or half row) every ~21-24 cycles whatever its length up to a few
-    // lines: a first version that cut 256-byte rows into two 128-byte pieces paid that price twice per row (16 KB per unit in
-    // 2 700 cycles = the whole phase).  Inside a piece, chunk cc of pair m sits at slot cc ^ key(m) of the pair's RC slots, which
+    // of 128 B): fewest distinct lines per instruction.  (Measured against pieces of 8 half rows x 128 B: the same 184-185 us at
+    // 1 M pairs — DESIGN 4.2 c.)  Inside a piece, chunk cc of pair m sits at slot cc ^ key(m) of the pair's RC slots, which
     // keeps the B-fragment read of a k-step (lane (m, h) <- chunk 2s+h of pair m's concatenated row) a conflict-free ds_read_b128:
     // its 16-lane groups hold 16 different m & 15 (RC = 16: key = m & 15) or 8 different keys in each 128-byte half (RC = 8).
     constexpr int NJ = NCU / 2;                              // pieces per table, wave and unit
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
             const unsigned char* const b1p = lds + L::OFF_B1 + (64 * g + 4 * kg) * 4;
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) asm volatile("" ::"v"(wa[0][ks]), "v"(wa[1][ks]), "v"(wa[2][ks]), "v"(wa[3][ks]));
-            wg_barrier();                                    // biases in LDS; B has rows(0 .. D-1) landed
+            wg_barrier();                                    // biases in LDS; the B waves have the rows of units 0 and 1 landed
 
             f32x4 acc[2][4][2];                              // [unit parity][row tile][column tile]
             u32x4 fr[RING];
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void score_ws8_bf16_kernel(Bf16Args a, cons
             auto xp = [&](unsigned xb, int s) { return reinterpret_cast<const u32x4*>(lds + (rdx[s % SIG] + xb) + (s / SIG) * TSTRIDE); };
 #pragma unroll
             for (int s = 0; s < Q1; ++s) asm volatile("" ::"v"(wa1[0][s]), "v"(wa1[1][s]));
-            wg_barrier();                                        // biases in LDS; B has rows(0 .. D-1) landed
+            wg_barrier();                                        // biases in LDS; the B waves have the rows of units 0 and 1 landed
 
             f32x16 acc[2][2];                                    // [unit parity][row tile]
             u32x4 fr[RING];
