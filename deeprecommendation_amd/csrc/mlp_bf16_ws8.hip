@@ -35,7 +35,7 @@
 #define NCF_WS8_ABLATE 0      // diagnostics: 1 = no row DMAs, 2 / 3 = rows from a 1 MiB / 64 MiB window of table A
 #endif
 #ifndef NCF_WS8_PRIO
-#define NCF_WS8_PRIO 0        // 1 = B waves at s_setprio 1, 2 = A waves at s_setprio 1
+#define NCF_WS8_PRIO 1        // 1 = B waves at s_setprio 1 (their MFMAs slot in ahead of the A stream: measured best together with NA = 0), 2 = A waves, 0 = none
 #endif
 #ifndef NCF_WS8_RING
 #define NCF_WS8_RING 4        // B-fragment register ring of a stream (reads run RING-1 k-steps ahead of their MFMA)
@@ -47,7 +47,7 @@
 #define NCF_WS8_STAGE 0       // 1 = B gathers through registers (global_load_dwordx4 -> ds_write_b128, all compiler-visible) instead of LDS-DMA
 #endif
 #ifndef NCF_WS8_NA
-#define NCF_WS8_NA 2          // row-DMA pieces (of the NCU per unit and pair group) issued by the A wave, after its MFMA stream
+#define NCF_WS8_NA 0          // row-DMA pieces (of the NCU per unit and pair group) issued by the A wave, after its MFMA stream (0: B issues all)
 #endif
 #ifndef NCF_WS8_SPREAD
 #define NCF_WS8_SPREAD 3      // B: one row DMA every this many layer-2 k-steps (0 = all DMAs at the head of the phase)
