@@ -847,7 +847,7 @@ int bf16_score(const void* tabA, int64_t rowsA, int64_t ldA, const void* tabB, i
     //   * ws8, the 8-wave weight-stationary kernel (mlp_bf16_ws8.hip), for the NCF shape it is built for: two tables of equal width
     //     (EA = EB = K0/2 in {64, 128}), MLP K0-256-128-1, ids given.  tools/ab_bf16_opt.py (E = 128, 4 M + 1 M rows), ws8 vs ws vs
     //     stream: 16 384 pairs 10.1 / 10.9 / 14.4 us, 32 768: 11.9 / 12.8 / 15.0, 65 536: 16.9 / 18.3 / 18.0, 131 072: 28.3 / 30.2 / 34.4,
-    //     262 144: 51.7 / 54.9 / 71.8, 1 M: 185 / 213-222 / 288, 4 M: 716-740 / 821-870 / 1 115; below 16 384 pairs all are launch-bound;
+    //     262 144: 51.7 / 54.9 / 71.8, 1 M: 174-181 / 210-222 / 288, 4 M: 694-696 / 821-870 / 1 115; below 16 384 pairs all are launch-bound;
     //   * ws, the 4-wave weight-stationary kernel, whenever the row widths are whole 128-byte units and ids are given;
     //   * the slab-streaming kernel otherwise.
     const int force = option(NCF_OPT_BF16_KERNEL);
