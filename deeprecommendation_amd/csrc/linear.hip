@@ -178,9 +178,11 @@ __global__ __launch_bounds__(KS > 4 ? KS * 64 : 256) void linear_rs_kernel(const
 
     const int Q = K / 8;
     // KS >= 8 (skinny and deep): the whole 32-wide blocks of K go through the staged loop below, split over the waves; what is
-    // left of K (< 32) is the last wave's, on the direct path
-    const int qlo = KS >= 8 ? (ks == KS - 1 ? 4 * (K / 32) : 0) : (int)((int64_t)ks * Q / KS);
-    const int qhi = KS >= 8 ? (ks == KS - 1 ? Q : 0) : (int)((int64_t)(ks + 1) * Q / KS);
+    // left of K (< 32) is ONE wave's, on the direct path
+    // (wave 0: the integer split gives the LAST wave the extra block, so the remainder goes to the first)
+    constexpr int TAILW = KS >= 8 ? 0 : KS - 1;              // the wave that owns the ragged end of K
+    const int qlo = KS >= 8 ? (ks == TAILW ? 4 * (K / 32) : 0) : (int)((int64_t)ks * Q / KS);
+    const int qhi = KS >= 8 ? (ks == TAILW ? Q : 0) : (int)((int64_t)(ks + 1) * Q / KS);
     if (tile_ok) {
       if constexpr (KS >= 8) {
         // Staged form.  Read straight into MFMA operand layout (lane = row), a 16-byte load per lane touches 32 rows: 32 pieces of
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(KS > 4 ? KS * 64 : 256) void linear_rs_kernel(const
             }
         }
       }
-        if ((K & 7) && ks == KS - 1) {  // ragged tail of K: guarded scalar loads, zero fill
+        if ((K & 7) && ks == TAILW) {  // ragged tail of K: guarded scalar loads, zero fill
             RsFrag<NT> t;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -473,7 +475,7 @@ static void launch_rs_nt(const float* A, int64_t lda, const float* W, int64_t ld
             // 4096 x 2094 -> 64: 36.5 -> 29.9 us, 2048 rows 27.1 -> 26.0; NOT beyond 256 workgroups (8192 rows: 48.8 -> 61.0,
             // N = 128: 47.2 -> 55.5) and 16 slices lose everywhere (tools/ab_linear_env.py, ncf_set_option("linear_kslices", 4|8) forces one)
             const int ksf = option(NCF_OPT_LINEAR_KSLICES);
-            // (staged A / W blocks since round 2: 4096 x 2094 -> 64 21.6 us vs 36.4 on 4 slices, 8192 rows 41.1 vs 48.1, N = 128 38.5 vs
+            // (staged A / W blocks since round 2: 4096 x 2094 -> 64 20.8 us vs 36.4 on 4 slices, 8192 rows 37.7 vs 48.1, N = 128 36.3 vs
             // 46.4, 4096 x 1030 -> 64 13.4 vs 18.1: tools/ab_skinny_linear.py)
             const bool ks8 = ksf ? ksf == 8 : K >= 1024;
             if (ks8) return launch_rs<1, 8>(A, lda, W, ldw, bias, C, ldc, M, K, relu, s, NT);
