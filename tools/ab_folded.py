@@ -16,7 +16,7 @@ def build_variant(i, flags):
     out = os.path.join(ROOT, "gpurun_out", "ab")
     os.makedirs(out, exist_ok=True)
     lib = os.path.join(out, f"libfold_v{i}.so")
-    srcs = [os.path.join(B.HERE, s) for s in ("abi.hip", "mlp_fused.hip", "mlp_bf16.hip")]
+    srcs = [os.path.join(B.HERE, s) for s in ("abi.hip", "mlp_fused.hip", "mlp_bf16.hip", "mlp_bf16_ws8.hip")]
     subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared", "-o", lib] + flags.split() + srcs)
     return lib
 
