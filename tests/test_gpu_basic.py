@@ -576,12 +576,13 @@ def test_linear_kernels_agree_with_float64(native, gpu, kernel_option, M, K, N, 
     assert_close(out, ref.float())
 
 
-@pytest.mark.parametrize("M,K,N", [(4096, 2094, 64), (1000, 2094, 64), (4100, 1030, 128), (33, 2094, 64)])
+@pytest.mark.parametrize("M,K,N", [(4096, 2094, 64), (1000, 2094, 64), (4100, 1030, 128), (33, 2094, 64), (500, 2048, 64), (700, 96, 64), (64, 40, 32)])
 @pytest.mark.parametrize("ks", ["4", "8", None])
 def test_skinny_split_k_widths_agree_with_float64(native, gpu, kernel_option, M, K, N, ks):
     """Skinny-deep Linear (AttentionNCF's F = 2094 candidate layer): K split over 4 or 8 waves of a workgroup, partial
     sums added through LDS in slice order; forced either way and by the shape rule, against a float64 product (K % 8 != 0
-    tail, ragged last row block)."""
+    tail, ragged last row block; for the 8-slice form, whose operand blocks are staged through LDS: K a whole number of 32-wide
+    blocks, fewer blocks than waves, and K below one block)."""
     if ks is None:
         kernel_option("linear_kslices", "auto")
     else:
