@@ -202,9 +202,9 @@ def _graph_worker(rank, world, store_path, mode, hetero):
         dist.destroy_process_group()
 
 
-def _spawn(fn, *args):
+def _spawn(fn, *args, world=2):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(fn, args=(2, os.path.join(d, "store")) + args, nprocs=2, join=True)
+        mp.spawn(fn, args=(world, os.path.join(d, "store")) + args, nprocs=world, join=True)
 
 
 @pytest.mark.parametrize("replicate_items", [False, True])
@@ -228,3 +228,17 @@ def test_partitioned_lightgcn_rejects_other_convolutions():
 @pytest.mark.parametrize("hetero", [True, False])
 def test_partitioned_lightgcn_world2(mode, hetero):
     _spawn(_graph_worker, mode, hetero)
+
+
+@pytest.mark.parametrize("exchange", ["unique", "bounded"])
+def test_row_sharded_basic_ncf_world3(exchange):
+    """Three ranks: shards of unequal length (1001 and 77 rows over 3), every rank both asks and serves, and the overflow / out-of-range
+    cases leave the two other ranks' collectives matched."""
+    _spawn(_sharded_worker, False, exchange, world=3)
+
+
+@pytest.mark.parametrize("mode", ["dst", "edge"])
+def test_partitioned_lightgcn_world3(mode):
+    """Three ranks: the uneven block exchange posts its sends and receives peer by peer in a staggered order — with more than two
+    ranks a mismatched order would deadlock here."""
+    _spawn(_graph_worker, mode, True, world=3)
