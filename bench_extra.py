@@ -548,26 +548,28 @@ def run_cfg5(args, ctx):
     # the same kernel on a 16x larger local batch (north_star: ">= 50 % MFMA utilisation on the MLP at emb_dim = 128"); skipped
     # under the profiler (--no-variants): the same kernel name at another size would pollute rocprof's per-kernel average —
     # that point has its own context (NCF_CFG5_LOCAL_BATCH=1048576 -> profiles/<tag>_cfg5_b1048576_*)
-    BL = 16 * B
-    big_variant = None
+    big_variants = {}
     if big:
-        lu2 = torch.randint(0, tu.shape[0], (BL,), device=device, generator=gl)
-        li2 = torch.randint(0, ti.shape[0], (BL,), device=device, generator=gl)
-        outl = torch.empty((BL, 1), device=device)
-        ktl = bench.kernel_time("ncf::score_ws8_bf16_kernel", f"cfg5_b{BL}", lambda: native.score_fused(tu, lu2, ti, li2, model.packed, out=outl), reps=30, settle=10)
-        tfl = flop * BL / (ktl["us"] * 1e-6) / 1e12
-        big_variant = {"kernel": "score_ws8_bf16_kernel<256,true>", "us_per_launch": ktl["us"], "us_per_launch_basis": ktl["basis"],
-                       "us_back_to_back": ktl["us_back_to_back"], "rocprof_avg_us": ktl["rocprof_avg_us"], "profile": ktl["profile"],
-                       "pairs_per_s": BL / (ktl["us"] * 1e-6), "achieved_TFLOPs": tfl, "frac_of_bf16_mfma_peak": tfl / bench.PEAK_BF16_MFMA_TFLOPS,
-                       "hbm_GBps_at_this_rate": 532 * BL / (ktl["us"] * 1e-6) / 1e9}
-        dg = bench.profile_digest("ncf::score_ws8_bf16_kernel", f"cfg5_b{BL}")
-        if dg and dg.get("held_clock_GHz"):
-            big_variant["held_clock_GHz_under_counters"] = dg["held_clock_GHz"]
-            big_variant["mfma_busy_frac_of_held_cycles"] = dg.get("mfma_busy_frac_of_held_cycles")
-            big_variant["note"] = ("the 2.5 PF peak assumes 2.4 GHz; under this kernel the chip holds the clock above (GRBM_GUI_ACTIVE / 8 / "
-                                   "kernel time in the PMC pass of the same context); the same binary on all-zero operands runs at 0.56 "
-                                   "of 2.5 PF (DESIGN 4.2 c)")
-        del lu2, li2, outl
+        for BL, reps in ((16 * B, 30), (64 * B, 12)):
+            lu2 = torch.randint(0, tu.shape[0], (BL,), device=device, generator=gl)
+            li2 = torch.randint(0, ti.shape[0], (BL,), device=device, generator=gl)
+            outl = torch.empty((BL, 1), device=device)
+            ktl = bench.kernel_time("ncf::score_ws8_bf16_kernel", f"cfg5_b{BL}", lambda: native.score_fused(tu, lu2, ti, li2, model.packed, out=outl), reps=reps, settle=10)
+            tfl = flop * BL / (ktl["us"] * 1e-6) / 1e12
+            bv = {"kernel": "score_ws8_bf16_kernel<256,true>", "us_per_launch": ktl["us"], "us_per_launch_basis": ktl["basis"],
+                  "us_back_to_back": ktl["us_back_to_back"], "rocprof_avg_us": ktl["rocprof_avg_us"], "profile": ktl["profile"],
+                  "pairs_per_s": BL / (ktl["us"] * 1e-6), "achieved_TFLOPs": tfl, "frac_of_bf16_mfma_peak": tfl / bench.PEAK_BF16_MFMA_TFLOPS,
+                  "frac_back_to_back": flop * BL / (ktl["us_back_to_back"] * 1e-6) / 1e12 / bench.PEAK_BF16_MFMA_TFLOPS,
+                  "hbm_GBps_at_this_rate": 532 * BL / (ktl["us"] * 1e-6) / 1e9}
+            dg = bench.profile_digest("ncf::score_ws8_bf16_kernel", f"cfg5_b{BL}")
+            if dg and dg.get("held_clock_GHz"):
+                bv["held_clock_GHz_under_counters"] = dg["held_clock_GHz"]
+                bv["mfma_busy_frac_of_held_cycles"] = dg.get("mfma_busy_frac_of_held_cycles")
+                bv["note"] = ("the 2.5 PF peak assumes 2.4 GHz; under this kernel the chip holds the clock above (GRBM_GUI_ACTIVE / 8 / "
+                              "kernel time in the PMC pass of the same context); the same binary on all-zero operands runs at 0.56 "
+                              "of 2.5 PF (DESIGN 4.2 c)")
+            big_variants[f"local_batch_{BL}"] = bv
+            del lu2, li2, outl
     if rank != 0:
         return None
     line = {"metric": "scored user-item pairs/sec", "value": world * B * args.steps / main_wall, "unit": "pairs/s", "n_gpus": world,
@@ -586,7 +588,7 @@ def run_cfg5(args, ctx):
                          "algorithmic_flop_per_pair": flop, "algorithmic_bytes_per_pair": 532,
                          "algorithmic_bytes_per_launch": 532 * B, "hbm_GBps_at_this_rate": 532 * B / (us * 1e-6) / 1e9,
                          "rocprof_avg_us": kt["rocprof_avg_us"], "profile": kt["profile"]},
-            "variants": {f"local_batch_{BL}": big_variant}}
+            "variants": big_variants}
     if world == 1 and not getattr(args, "no_cpu_baseline", False):
         line["cpu_baseline"] = _cfg5_cpu_baseline(ws, bs, E, B)
     return line
