@@ -148,6 +148,7 @@ class IndexGraphProvider(GraphContentProvider):
         unode = upos + I
         k1 = np.ones(len(r), bool) if not binary else r >= user_avg
         k2 = np.ones(len(r), bool) if not binary else r >= item_avg
+        self._pos_parts = (unode, ipos, k1, k2)
         self.graph = GraphData(
             item_features=None, user_features=None,
             user2item_edge_index=torch.from_numpy(np.stack([unode[k1], ipos[k1]])),
@@ -178,6 +179,18 @@ class IndexGraphProvider(GraphContentProvider):
 
     def get_graph(self) -> GraphData:
         return self.graph
+
+    def pos_df(self):
+        """The reference's ``pos_df`` (graph_providers.py:24,37,46,54-55): MultiIndex (Id1, Id2) -> position of the edge inside its
+        direction's edge list, rows in the reference's order (per interaction: the user->item row, then the item->user row).
+        Built on demand — the models here mask target edges by key (``PreparedGraph.masked_coef``), not through this frame."""
+        import pandas as pd
+        unode, ipos, k1, k2 = self._pos_parts
+        n = len(unode)
+        rows = np.concatenate([np.stack([unode[k1], ipos[k1], np.arange(int(k1.sum()))], 1),
+                               np.stack([ipos[k2], unode[k2], np.arange(int(k2.sum()))], 1)])
+        order = np.argsort(np.concatenate([2 * np.arange(n)[k1], 2 * np.arange(n)[k2] + 1]), kind="stable")
+        return pd.DataFrame(rows[order], columns=["Id1", "Id2", "pos"]).set_index(["Id1", "Id2"], inplace=False)
 
 
 class SparseDynamicProvider(DynamicContentProvider):

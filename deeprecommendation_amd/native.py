@@ -548,6 +548,15 @@ def attn_grouped_supported(mode: int, A: int, Fdim: int) -> bool:
     return mode in (ATT_MLP, ATT_COS, ATT_MLP_SCALED) and A % 4 == 0 and A <= 256 and Fdim <= 256
 
 
+def attn_backward_supported(mode: int, A: int, Fdim: int) -> bool:
+    """Shapes the training pair ``ncf_attn_forward`` + ``ncf_attn_backward`` takes: mirrors ncf_attn_backward's own
+    NCF_EUNSUPPORTED conditions (csrc/attn.hip: MLP / cosine only; A and Fdim multiples of 4 and <= 256 — the leading
+    dimensions are those of contiguous (.., A) / (.., Fdim) tensors, so they are multiples of 4 when A and Fdim are).  The
+    plain forward accepts any Fdim through its generic path, so a gate on the forward's conditions would let
+    ``loss.backward()`` raise for e.g. user_emb = 50."""
+    return mode in (ATT_MLP, ATT_COS, ATT_MLP_SCALED) and A % 4 == 0 and Fdim % 4 == 0 and 0 < A <= 256 and 0 < Fdim <= 256
+
+
 def default_pairs_per_wg(B: int) -> int:
     """Pairs of one rated set per workgroup of the grouped attention kernel (4 per wave).  32 (512 threads) stages a tile
     for twice as many pairs as 16 (256 threads): half the gathered bytes per pair, and the tile DMAs hold a wave for about a

@@ -323,7 +323,7 @@ class AttentionNCF(_ScoringMixin, NCF):
 
     def _forward_train(self, candidate_items, rated_items, user_matrix, return_attention_weights):
         hip = (candidate_items.is_cuda and not getattr(self, "train_with_torch_ops", False) and not (self.training and self.message_dropout)
-               and (self.use_cos_sim_instead or self.att_dense) and native.attn_grouped_supported(
+               and (self.use_cos_sim_instead or self.att_dense) and native.attn_backward_supported(
                    native.ATT_COS if self.use_cos_sim_instead else native.ATT_MLP,
                    self.ItemEmbeddings[0].out_features if self.use_cos_sim_instead else int(self.att_dense), self.UserEmbeddings[0].out_features))
         if hip:

@@ -131,8 +131,9 @@ def mf_forward_indexed(state: State, user_pos: torch.Tensor, item_pos: torch.Ten
 # --------------------------------------------------------------------------------------
 def attention_ncf_forward(state: State, candidate_items: torch.Tensor, rated_items: torch.Tensor,
                           user_matrix: torch.Tensor, use_cos_sim_instead: bool = False,
-                          return_attention_weights: bool = False):
-    """models/attention_ncf.py:136-224 with ``self.training == False``.
+                          return_attention_weights: bool = False, training: bool = False):
+    """models/attention_ncf.py:136-224; ``training`` = ``self.training`` with every Dropout at p = 0 and
+    ``message_dropout=None`` (the deterministic train mode): the only train-only step left is the target mask (:195-205).
 
     Reference-faithful: materialises all B*I candidate/rated pairs (:154-155), keeps the valid ones
     (``user_matrix != 0``, :158-159), scores them with AttentionNet (:176-179) or cosine similarity
@@ -160,6 +161,11 @@ def attention_ncf_forward(state: State, candidate_items: torch.Tensor, rated_ite
         att_out = mlp_forward(att_in, att_layers).view(-1)  # :179
     scores = -float("inf") * torch.ones((B, I), dtype=torch.float32)  # :182
     scores[valid] = att_out  # :192
+    if training:
+        # :195-205 — a candidate whose EMBEDDING equals a rated item's (isclose, atol 1e-5, every element) is removed from
+        # its own softmax row, whether or not the user rated it
+        same = torch.isclose(cand_full, rated_full, atol=1e-5).all(dim=1).view(B, I)  # :199
+        scores[same] = -float("inf")  # :203
     scores = F.softmax(scores, dim=1)  # :208
     scores = scores.nan_to_num(nan=0.0, posinf=0.0, neginf=0.0)  # :209
     attended = torch.mul(scores, user_matrix)  # :212
@@ -167,7 +173,22 @@ def attention_ncf_forward(state: State, candidate_items: torch.Tensor, rated_ite
     user_emb = F.linear(user_feat, state["UserEmbeddings.0.weight"], state["UserEmbeddings.0.bias"])  # :216
     combined = torch.cat((cand_emb, user_emb), dim=1)  # :219  candidate first
     out = mlp_forward(combined, mlp_weights(state))  # :222
-    return (out, scores) if return_attention_weights else out
+    return (out, scores.detach()) if return_attention_weights else out  # :224
+
+
+def mse_sum_loss(y_pred: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
+    """datasets/base.py:19-20,31-32: ``nn.MSELoss(reduction='sum')(y_pred, y_true.view(-1, 1).float())``."""
+    return F.mse_loss(y_pred, y_true.view(-1, 1).float(), reduction="sum")
+
+
+def loss_and_grads(forward, state: State, y: torch.Tensor):
+    """Reference training step up to ``loss.backward()`` (train.py:99-107) through a functional forward of this file:
+    returns (out, loss, {state key: d loss / d parameter}).  ``forward(state)`` must return the (B, 1) prediction."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in state.items()}
+    out = forward(leaf)
+    loss = mse_sum_loss(out, y)
+    loss.backward()
+    return out.detach(), loss.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
 
 
 # --------------------------------------------------------------------------------------

@@ -17,6 +17,44 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- observed parity margins: every comparison records how much of its bar it used; one summary at session end ----
+_MARGINS = {}
+
+
+def record_error(tag, err, bar, scale_rel=None):
+    """``err`` / ``bar`` of one comparison (same units).  Kept per test (worst comparison wins); printed at session end and
+    written to gpurun_out/parity_margins.json so that the distance to the 1e-5 bar is on record, not just pass / fail."""
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    key = f"{test}|{tag}" if tag else test
+    frac = float(err) / float(bar) if bar else float("inf") if err else 0.0
+    old = _MARGINS.get(key)
+    if old is None or frac > old["frac_of_bar"]:
+        _MARGINS[key] = {"err": float(err), "bar": float(bar), "frac_of_bar": frac,
+                         "max_err_over_max_ref": None if scale_rel is None else float(scale_rel)}
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not _MARGINS:
+        return
+    rows = sorted(_MARGINS.items(), key=lambda kv: -kv[1]["frac_of_bar"])
+    fr = np.array([v["frac_of_bar"] for _, v in rows])
+    rel = np.array([v["max_err_over_max_ref"] for _, v in rows if v["max_err_over_max_ref"] is not None])
+    tr = terminalreporter
+    tr.write_sep("-", "parity margins (observed error / bar)")
+    tr.write_line(f"{len(rows)} recorded comparisons: worst {fr.max():.3f} of its bar, median {np.median(fr):.3f}; "
+                  + (f"max|a-b|/max|ref| worst {rel.max():.2e}, median {np.median(rel):.2e}" if len(rel) else ""))
+    for k, v in rows[:8]:
+        tr.write_line(f"  {v['frac_of_bar']:.3f} of bar (err {v['err']:.3e}, bar {v['bar']:.3e})  {k}")
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_margins.json"), "w") as f:
+            json.dump({"n": len(rows), "worst_frac_of_bar": float(fr.max()), "median_frac_of_bar": float(np.median(fr)),
+                       "worst_max_err_over_max_ref": float(rel.max()) if len(rel) else None, "entries": dict(rows)}, f, indent=1)
+    except OSError:
+        pass
+
+
 def load_golden(name):
     """Returns (state_dict of torch tensors, dict of other arrays, kwargs dict or None)."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
@@ -24,6 +62,8 @@ def load_golden(name):
     for k in z.files:
         if k.startswith("w::"):
             state[k[3:]] = torch.from_numpy(z[k])
+        elif k.startswith("g::"):      # reference parameter gradients (round 3 fixtures): arrays["grads"][state key]
+            arrays.setdefault("grads", {})[k[3:]] = torch.from_numpy(z[k])
         else:
             arrays[k] = z[k]
     kwargs = json.loads(str(arrays.pop("kwargs"))) if "kwargs" in arrays else None

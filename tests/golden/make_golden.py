@@ -13,6 +13,11 @@ The reference imports ``torch_geometric.data.Data`` (content_providers.py:1, ann
 ``seaborn`` (plots.py:3); neither is installed, so two empty in-memory stub modules are registered
 before the import.  GraphNCF cannot be imported (needs torch_geometric.nn) -> no golden for it
 (parity unpinned; see oracle/ncf_oracle.py header).
+
+Round 3 adds the deterministic train-mode pins:
+  g3_att_train_*   AttentionNCF in .train() with dropout_rate=0.0 / message_dropout=None: target masking (:195-205)
+  g7_grads_*       loss = MSELoss(reduction='sum') (datasets/base.py:19-20,31-32), .backward(): every parameter gradient
+  g8_create_graph_*  content_providers/graph_providers.py:10-66 create_graph, binary and weighted
 """
 import hashlib
 import json
@@ -32,8 +37,10 @@ def _import_reference():
     tg = types.ModuleType("torch_geometric")
     tgd = types.ModuleType("torch_geometric.data")
 
-    class Data:  # annotation-only stub
-        pass
+    class Data:  # attribute bag: the reference uses it as an annotation (content_providers.py:61) and, in create_graph
+        # (graph_providers.py:58-66), as a keyword container — no PyG behaviour is involved in either
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
 
     tgd.Data = Data
     tg.data = tgd
@@ -60,6 +67,7 @@ def main():
     from neural_collaborative_filtering.models.attention_ncf import AttentionNCF
     from neural_collaborative_filtering.util import build_MLP_layers
 
+    import pandas as pd
     torch.set_num_threads(1)
 
     def onehot(pos, n):
@@ -156,6 +164,93 @@ def main():
             out, att = m(cand, rated, um, return_attention_weights=True)
         _save(tag, candidate_items=cand.numpy(), rated_items=rated.numpy(), user_matrix=um.numpy(),
               out=out.numpy(), att=att.numpy(), kwargs=np.array(json.dumps(m.kwargs)), **_state_arrays(m))
+
+    # ---------------- G3-train: AttentionNCF.train(), deterministic (dropout 0, no message dropout) ----------------
+    # attention_ncf.py:195-205: in training a candidate that equals one of the rated rows (isclose on the embeddings) is
+    # masked out of its own softmax row.  Candidates 0..n_self-1 ARE rated rows of the batch; the loss is the reference's
+    # MSELoss(reduction='sum') against y (datasets/base.py:19-20,31-32) and every parameter gradient is stored.
+    def att_train_case(tag, Fdim, IE, UE, B, I, n_self, seed, mlp, density=0.5, **kw):
+        torch.manual_seed(seed)
+        m = AttentionNCF(item_dim=Fdim, item_emb=IE, user_emb=UE, mlp_dense_layers=mlp, dropout_rate=0.0,
+                         message_dropout=None, **kw).train()
+        g = torch.Generator().manual_seed(seed + 1)
+        rated = torch.rand(I, Fdim, generator=g)
+        cand = torch.rand(B, Fdim, generator=g)
+        self_cols = torch.randperm(I, generator=g)[:n_self]
+        cand[:n_self] = rated[self_cols]                      # these candidates are rated items of the batch
+        um = torch.zeros(B, I)
+        mask = torch.rand(B, I, generator=g) < density
+        um[mask] = (torch.randint(1, 11, (B, I), generator=g).float() * 0.5 - 2.9)[mask]
+        for b in range(n_self):                               # the user HAS rated the candidate (that is what gets masked)
+            um[b, self_cols[b]] = 1.35 if b % 2 == 0 else -0.65
+        um[B - 1] = 0.0                                       # all-unrated row in train mode
+        if n_self > 1:                                        # a row whose ONLY rated entry is the candidate itself -> all -inf -> 0
+            um[1] = 0.0
+            um[1, self_cols[1]] = 0.85
+        y = torch.randint(1, 11, (B,), generator=g).float() * 0.5
+        out, att = m(cand, rated, um, return_attention_weights=True)
+        loss = torch.nn.MSELoss(reduction='sum')(out, y.view(-1, 1).float())
+        loss.backward()
+        grads = {"g::" + k: p.grad.detach().numpy().copy() for k, p in m.named_parameters()}
+        assert all(np.isfinite(v).all() for v in grads.values())
+        _save(tag, candidate_items=cand.numpy(), rated_items=rated.numpy(), user_matrix=um.numpy(), y=y.numpy(),
+              self_cols=self_cols.numpy(), out=out.detach().numpy(), att=att.numpy(), loss=np.array(loss.item()),
+              kwargs=np.array(json.dumps(m.kwargs)), **_state_arrays(m), **grads)
+
+    att_train_case("g3_att_train_dense8", 20, 16, 16, 8, 12, 3, 201, [32, 16], att_dense=8)
+    att_train_case("g3_att_train_cos", 20, 16, 16, 8, 12, 3, 202, [32, 16], use_cos_sim_instead=True)
+    att_train_case("g3_att_train_vec64", 48, 64, 64, 40, 150, 9, 203, [256, 128], density=0.3, att_dense=128)
+    att_train_case("g3_att_train_ue50", 24, 16, 50, 8, 12, 2, 204, [32], att_dense=8)   # user_emb not a multiple of 4
+
+    # ---------------- G7: gradients of BasicNCF / MF under the reference's loss ----------------
+    def grads_case(tag, m, up, ip, U, I, seed):
+        g = torch.Generator().manual_seed(seed)
+        y = torch.randint(1, 11, (len(up),), generator=g).float() * 0.5
+        out = m(onehot(up, U), onehot(ip, I))
+        loss = torch.nn.MSELoss(reduction='sum')(out, y.view(-1, 1).float())
+        loss.backward()
+        grads = {"g::" + k: p.grad.detach().numpy().copy() for k, p in m.named_parameters()}
+        _save(tag, user_pos=up, item_pos=ip, y=y.numpy(), out=out.detach().numpy(), loss=np.array(loss.item()),
+              kwargs=np.array(json.dumps(m.kwargs)), **_state_arrays(m), **grads)
+
+    rng = np.random.default_rng(21)
+    torch.manual_seed(301)
+    U, I = 60, 40
+    m = BasicNCF(item_dim=I, user_dim=U, item_emb=8, user_emb=8, mlp_dense_layers=[16, 8], dropout_rate=None).train()
+    grads_case("g7_grads_basic_small", m, rng.integers(0, U, 96), rng.integers(0, I, 96), U, I, 31)   # duplicates in the batch
+    torch.manual_seed(302)
+    U, I = 300, 200
+    m = BasicNCF(item_dim=I, user_dim=U, item_emb=64, user_emb=64, mlp_dense_layers=[256, 128], dropout_rate=None).train()
+    grads_case("g7_grads_basic_e64", m, rng.integers(0, U, 500), rng.integers(0, I, 500), U, I, 32)
+    torch.manual_seed(303)
+    m = BasicNCF(item_dim=I, user_dim=U, item_emb=32, user_emb=32, mlp_dense_layers=[256], dropout_rate=None).train()
+    grads_case("g7_grads_basic_h256", m, rng.integers(0, U, 130), rng.integers(0, I, 130), U, I, 33)
+    torch.manual_seed(304)
+    m = MF(item_dim=40, user_dim=60, item_emb=16, user_emb=16).train()
+    grads_case("g7_grads_mf", m, rng.integers(0, 60, 96), rng.integers(0, 40, 96), 60, 40, 34)
+
+    # ---------------- G8: create_graph (content_providers/graph_providers.py:10-66) ----------------
+    from content_providers.graph_providers import create_graph
+    rng = np.random.default_rng(41)
+    all_users = np.arange(100, 145)
+    all_items = np.arange(0, 100)
+    n = 300
+    users = rng.integers(100, 140, n)
+    items = rng.integers(7, 30, n) * 3
+    ratings = rng.integers(1, 11, n) * 0.5
+    inter = pd.DataFrame({"userId": users, "movieId": items, "rating": ratings})
+    item_to_node = {int(i): k for k, i in enumerate(sorted(all_items))}                     # graph_providers.py:77-80
+    user_to_node = {int(u): len(all_items) + k for k, u in enumerate(sorted(all_users))}
+    for binary in (False, True):
+        gr = create_graph(inter, None, None, item_to_node, user_to_node, binary=binary)
+        pos = gr.pos_df.reset_index()[["Id1", "Id2", "pos"]].to_numpy().astype(np.int64)
+        extra = {}
+        if not binary:
+            extra = dict(user2item_edge_attr=gr.user2item_edge_attr.numpy(), item2user_edge_attr=gr.item2user_edge_attr.numpy())
+        _save("g8_create_graph_" + ("binary" if binary else "weighted"), all_users=all_users, all_items=all_items,
+              userId=users, movieId=items, rating=ratings,
+              user2item_edge_index=gr.user2item_edge_index.numpy(), item2user_edge_index=gr.item2user_edge_index.numpy(),
+              pos=pos, **extra)
 
     # ---------------- G4: shipped checkpoint (weights NOT copied) ----------------
     ck = os.path.join(REF, "models/runs/AttentionNCF_with_features_attNet128_3mil.pt")

@@ -382,3 +382,57 @@ def test_candidate_projections_are_kept_for_a_repeated_candidate_tensor(native, 
         m.ItemEmbeddings[0].bias.add_(0.5)                          # weight update -> everything derived is dropped
         fresh.load_state_dict(m.state_dict())
         assert torch.equal(m(other, feats, user_matrix(3)), fresh(other.clone(), feats, user_matrix(3)))
+
+
+def test_cfg3_bench_workload_full_size_grouped_kernel(gpu):
+    """The workload bench.py times for BASELINE config 3, at full size and through the model (bench_extra.cfg3_workload: 100 k-row
+    catalogue, F = 2094, 4096 pairs of 64 users x 256 rated): the forward takes the LDS-tiled grouped kernel
+    (attn_grouped_sc_kernel<NCF_ATT_MLP_SCALED, 32 pairs / workgroup, 8 waves>).  Checked (i) against the per-pair kernel on the
+    SAME batch (one CSR row per pair, a different kernel and summation order), 1e-5; (ii) a 16-pair slice against the CPU oracle's
+    reference formulation (attention_ncf.py:136-224) over the union of those users' rated items — the catalogue the reference's
+    provider would hand over (dynamic_profiles_provider.py:55-71: columns nobody in the batch rated do not exist there, and are
+    masked by `user_matrix != 0` here); (iii) with 4096 distinct users (no sharing: the model's per-pair dispatch) the same pairs
+    give the same scores."""
+    import bench_extra
+    from deeprecommendation_amd import native
+    I, B, nnz, Fdim, IE, UE, A = bench_extra.CFG3_DIMS
+    model, catalogue, batches = bench_extra.cfg3_workload(gpu, users=64, n_batches=1)
+    cand, r = batches[0]
+    assert r.pair_row is not None and r.pairs_per_row >= 4 and native.default_pairs_per_wg(B) == 32
+    with torch.no_grad():
+        out_g, att_g = model(cand, catalogue, r, return_attention_weights=True)         # grouped kernel
+        rx = r.expanded()
+        assert rx.pair_row is None
+        out_p, att_p = model(cand, catalogue, rx, return_attention_weights=True)        # per-pair kernel
+    assert out_g.shape == (B, 1)
+    assert_close(out_g, out_p)
+    assert float((att_g - att_p).abs().max()) <= 1e-6
+    sums = att_g.sum(1)
+    assert float((sums - 1).abs().max()) < 1e-5
+    # (ii) oracle on 16 pairs
+    sl = torch.arange(0, B, B // 16, device=gpu)[:16]
+    rows = r.pair_row[sl]
+    cols = r.col.view(64, nnz)[rows].long()                       # (16, 256) catalogue positions
+    rated_ids = torch.unique(cols)
+    um = torch.zeros(16, rated_ids.numel(), device=gpu)
+    um.scatter_(1, torch.searchsorted(rated_ids, cols), r.val.view(64, nnz)[rows])
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref, ref_att = O.attention_ncf_forward(state, cand[sl].cpu(), catalogue[rated_ids].cpu(), um.cpu(), return_attention_weights=True)
+    assert_close(out_g[sl], ref)
+    assert_close(att_g[sl][:, rated_ids], ref_att)
+    # (iii) 4096 distinct users: every pair has its own rated set (per-pair dispatch inside the model)
+    model2, catalogue2, batches2 = bench_extra.cfg3_workload(gpu, users=B, n_batches=1)
+    cand2, r2 = batches2[0]
+    assert int(torch.unique(r2.pair_row).numel()) == B
+    with torch.no_grad():
+        out2 = model2(cand2, catalogue2, r2)
+        out2x = model2(cand2, catalogue2, r2.expanded())
+    assert_close(out2, out2x)
+    sl2 = sl[:4]
+    rows2 = r2.pair_row[sl2]
+    cols2 = r2.col.view(B, nnz)[rows2].long()
+    ids2 = torch.unique(cols2)
+    um2 = torch.zeros(4, ids2.numel(), device=gpu)
+    um2.scatter_(1, torch.searchsorted(ids2, cols2), r2.val.view(B, nnz)[rows2])
+    state2 = {k: v.detach().cpu() for k, v in model2.state_dict().items()}
+    assert_close(out2[sl2], O.attention_ncf_forward(state2, cand2[sl2].cpu(), catalogue2[ids2].cpu(), um2.cpu()))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, onehot
+from conftest import load_golden, onehot, record_error
 from oracle import ncf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -23,6 +23,12 @@ def assert_close(a, ref, rtol=RTOL, floor=0.1):
     ref = ref.detach().cpu().double()
     assert a.shape == ref.shape
     tol = rtol * ref.abs() + floor * rtol * ref.abs().max()
+    if ref.numel():
+        diff = (a - ref).abs()
+        used = diff / tol.clamp_min(1e-300)          # fraction of the bar each element used
+        k = int(used.argmax())
+        record_error("", float(diff.flatten()[k]), float(tol.flatten()[k]),
+                     scale_rel=float(diff.max()) / max(float(ref.abs().max()), 1e-300))
     bad = (a - ref).abs() > tol
     assert not bool(bad.any()), f"max abs err {(a - ref).abs().max().item():.3e}, ref scale {ref.abs().max().item():.3e}"
 

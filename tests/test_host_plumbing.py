@@ -84,6 +84,25 @@ def test_index_graph_provider_matches_reference_loop(binary):
     assert g.num_items == 100 and g.num_users == 45
 
 
+@pytest.mark.parametrize("kind", ["weighted", "binary"])
+def test_index_graph_provider_matches_reference_create_graph_golden(kind):
+    """g8: the graph the REFERENCE's own create_graph (content_providers/graph_providers.py:10-66) builds from the same
+    interactions — edge lists in the same order, edge weights, and the pos_df rows."""
+    _, a, _ = load_golden("g8_create_graph_" + kind)
+    gp = IndexGraphProvider(a["all_users"], a["all_items"], a["userId"], a["movieId"], a["rating"], binary=(kind == "binary"))
+    g = gp.get_graph()
+    assert np.array_equal(g.user2item_edge_index.numpy(), a["user2item_edge_index"])
+    assert np.array_equal(g.item2user_edge_index.numpy(), a["item2user_edge_index"])
+    if kind == "binary":
+        assert g.user2item_edge_attr is None and g.item2user_edge_attr is None
+        assert g.user2item_edge_index.shape[1] < len(a["userId"])          # the rating >= neutral filter dropped edges
+    else:
+        # the reference rounds python floats (float64 arithmetic) to float32 once: torch.tensor(list, dtype=float)
+        assert np.array_equal(g.user2item_edge_attr.numpy(), a["user2item_edge_attr"])
+        assert np.array_equal(g.item2user_edge_attr.numpy(), a["item2user_edge_attr"])
+    assert np.array_equal(gp.pos_df().reset_index()[["Id1", "Id2", "pos"]].to_numpy(), a["pos"])
+
+
 def test_sparse_dynamic_provider_matches_dense_reference_form():
     rng = np.random.default_rng(2)
     item_ids = np.arange(1000, 1040)

@@ -173,3 +173,45 @@ def test_c_kernel_order_oracle_agrees_with_reference_level_oracle():
     out = c_oracle.score_fused_f32(tu, ti, torch.as_tensor(a["user_pos"][sub].astype(np.int64)),
                                    torch.as_tensor(a["item_pos"][sub].astype(np.int64)), [w for w, _ in layers], [b for _, b in layers])
     assert torch.allclose(out, torch.from_numpy(a["out"][sub]), rtol=1e-5, atol=1e-6)
+
+
+# ---------------- round 3: deterministic train-mode pins (target mask, gradients) ----------------
+@pytest.mark.parametrize("name", ["g3_att_train_dense8", "g3_att_train_cos", "g3_att_train_vec64", "g3_att_train_ue50"])
+def test_attention_train_mode_target_mask_and_gradients(name):
+    """attention_ncf.py:195-205 (train-only target mask) and the gradients of MSELoss(sum) (datasets/base.py:31-32)."""
+    state, a, kw = load_golden(name)
+    cand, rated, um = (torch.from_numpy(a[k]) for k in ("candidate_items", "rated_items", "user_matrix"))
+    out, att = O.attention_ncf_forward(state, cand, rated, um, use_cos_sim_instead=kw["use_cos_sim_instead"],
+                                       return_attention_weights=True, training=True)
+    assert torch.equal(out, torch.from_numpy(a["out"]))
+    assert torch.equal(att, torch.from_numpy(a["att"]))
+    for b, c in enumerate(a["self_cols"]):           # the fixture's self-rated candidates are masked ...
+        assert float(att[b, c]) == 0.0 and float(um[b, c]) != 0.0
+    ev = O.attention_ncf_forward(state, cand, rated, um, use_cos_sim_instead=kw["use_cos_sim_instead"], return_attention_weights=True)[1]
+    assert float(ev[0, a["self_cols"][0]]) > 0.0     # ... and are not in eval mode
+    assert float(att[1].abs().sum()) == 0.0          # row whose only entry is the candidate itself: all -inf -> 0
+    _, loss, grads = O.loss_and_grads(
+        lambda st: O.attention_ncf_forward(st, cand, rated, um, use_cos_sim_instead=kw["use_cos_sim_instead"], training=True),
+        state, torch.from_numpy(a["y"]))
+    assert float(loss) == float(a["loss"])
+    assert set(grads) == set(a["grads"])
+    for k, g in a["grads"].items():
+        assert torch.equal(grads[k], g), k
+
+
+@pytest.mark.parametrize("name", ["g7_grads_basic_small", "g7_grads_basic_e64", "g7_grads_basic_h256", "g7_grads_mf"])
+def test_basic_and_mf_gradients(name):
+    state, a, kw = load_golden(name)
+    fwd = O.mf_forward if name.endswith("_mf") else O.basic_ncf_forward
+    Xu, Xi = onehot(a["user_pos"], kw["user_dim"]), onehot(a["item_pos"], kw["item_dim"])
+    out, loss, grads = O.loss_and_grads(lambda st: fwd(st, Xu, Xi), state, torch.from_numpy(a["y"]))
+    assert torch.equal(out, torch.from_numpy(a["out"])) and float(loss) == float(a["loss"])
+    for k, g in a["grads"].items():
+        assert torch.equal(grads[k], g), k
+    if not name.endswith("_mf"):
+        # table formulation: same loss; embedding gradients are the scatter-add the dense one-hot GEMM performs
+        _, loss2, g2 = O.loss_and_grads(lambda st: O.basic_ncf_forward_indexed(st, torch.as_tensor(a["user_pos"]), torch.as_tensor(a["item_pos"])),
+                                        state, torch.from_numpy(a["y"]))
+        assert float(loss2) == float(a["loss"])
+        for k, g in a["grads"].items():
+            assert torch.allclose(g2[k], g, rtol=1e-5, atol=1e-6 * float(g.abs().max())), k
