@@ -142,7 +142,11 @@ def run_cfg4(args, ctx):
     gbs = alg / (us * 1e-6) / 1e9
     dig = bench.profile_digest("ncf::spmm_layer", "cfg4") or {}   # tools/summarize_profile.py: the layer's launches summed
     traffic = dig.get("traffic")
-    hbm_gbs = None if traffic is None else traffic / (us * 1e-6) / 1e9
+    hbm_gbs_live = None if traffic is None else traffic / (us * 1e-6) / 1e9
+    # the counter bytes come from the committed profile: divide them by THAT profile's own layer time (same run, same clock);
+    # the live layer time gives frac_live beside it
+    prof_us = dig.get("rocprof_avg_us")
+    hbm_gbs = hbm_gbs_live if (traffic is None or not prof_us) else traffic / (prof_us * 1e-6) / 1e9
     line = {"metric": "LightGCN propagated directed edges/sec", "value": L * E * args.steps / wall, "unit": "edges/s", "n_gpus": 1,
             "steps": args.steps, "warmup": warm, "warmup_requested": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -154,7 +158,8 @@ def run_cfg4(args, ctx):
                          # the L2's memory side (FETCH x2 + WRITE) per layer over the layer's time; the algorithmic rate beside it
                          "achieved": hbm_gbs if hbm_gbs is not None else gbs, "peak": bench.PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": (hbm_gbs if hbm_gbs is not None else gbs) / bench.PEAK_HBM_GBS,
-                         "frac_basis": "PMC bytes per layer / layer time" if hbm_gbs is not None else "ALGORITHMIC bytes / layer time (no committed PMC profile)",
+                         "frac_basis": ("PMC bytes per layer / the same profile's layer time" if prof_us else "PMC bytes per layer / live layer time") if hbm_gbs is not None else "ALGORITHMIC bytes / live layer time (no committed PMC profile)",
+                         "frac_live": None if hbm_gbs_live is None else hbm_gbs_live / bench.PEAK_HBM_GBS,
                          "traffic": traffic, "us_per_launch": us, "us_isolated_events": kt["us_isolated_events"],
                          "rocprof_layer_us": dig.get("rocprof_avg_us"), "profile": dig.get("profile"),
                          "algorithmic_bytes_per_edge": bytes_per_edge, "algorithmic_bytes_per_launch": alg,
@@ -376,7 +381,7 @@ def run_cfg3(args, ctx):
                          "algorithmic_bytes_per_launch": bpp * B, "hbm_GBps_at_this_rate": bpp * B / (us * 1e-6) / 1e9,
                          "per_pair_kernel_us": us_pp, "grouped_kernel_us": us_g, "grouping_prep_us": us_group_prep,
                          "pairs_per_workgroup": ppw, "candidate_linear_us": lin_us,
-                         "rocprof_avg_us": kt["rocprof_avg_us"], "profile": kt["profile"],
+                         "rocprof_avg_us": kt["rocprof_avg_us"], "profile": kt["profile"], "profile_check": kt["profile_check"],
                          "note": "bound = fp32 vector (VALU) issue: the contract's hbm/mfma pair does not describe this kernel — its tiles come "
                                  "from L2 / the Infinity Cache once per workgroup (hbm_GBps_at_this_rate is what it NEEDS, a few % of HBM), "
                                  "and relu sits between the add and the dot, so the matrix cores cannot take the (pair, entry, a) loop; "
@@ -575,7 +580,7 @@ def run_cfg5(args, ctx):
             ktl = bench.kernel_time("ncf::score_ws8_bf16_kernel", f"cfg5_b{BL}", lambda: native.score_fused(tu, lu2, ti, li2, model.packed, out=outl), reps=reps, settle=10)
             tfl = flop * BL / (ktl["us"] * 1e-6) / 1e12
             bv = {"kernel": "score_ws8_bf16_kernel<256,true>", "us_per_launch": ktl["us"], "us_per_launch_basis": ktl["basis"],
-                  "us_back_to_back": ktl["us_back_to_back"], "rocprof_avg_us": ktl["rocprof_avg_us"], "profile": ktl["profile"],
+                  "us_back_to_back": ktl["us_back_to_back"], "rocprof_avg_us": ktl["rocprof_avg_us"], "profile": ktl["profile"], "profile_check": ktl["profile_check"],
                   "pairs_per_s": BL / (ktl["us"] * 1e-6), "achieved_TFLOPs": tfl, "frac_of_bf16_mfma_peak": tfl / bench.PEAK_BF16_MFMA_TFLOPS,
                   "frac_back_to_back": flop * BL / (ktl["us_back_to_back"] * 1e-6) / 1e12 / bench.PEAK_BF16_MFMA_TFLOPS,
                   "hbm_GBps_at_this_rate": 532 * BL / (ktl["us"] * 1e-6) / 1e9}
@@ -605,7 +610,7 @@ def run_cfg5(args, ctx):
                          "us_per_launch_basis": kt["basis"], "us_back_to_back": us_b2b, "us_isolated_events": kt["us_isolated_events"],
                          "algorithmic_flop_per_pair": flop, "algorithmic_bytes_per_pair": 532,
                          "algorithmic_bytes_per_launch": 532 * B, "hbm_GBps_at_this_rate": 532 * B / (us * 1e-6) / 1e9,
-                         "rocprof_avg_us": kt["rocprof_avg_us"], "profile": kt["profile"]},
+                         "rocprof_avg_us": kt["rocprof_avg_us"], "profile": kt["profile"], "profile_check": kt["profile_check"]},
             "variants": big_variants}
     if world == 1 and not getattr(args, "no_cpu_baseline", False):
         line["cpu_baseline"] = _cfg5_cpu_baseline(ws, bs, E, B)

@@ -36,6 +36,7 @@ def _compare(model, a, out, att, loss, tag, rtol=1e-5):
     named = dict(model.named_parameters())
     assert set(named) == set(a["grads"])
     worst = 0.0
+    noise = 1e-8 * abs(float(a["loss"]))
     for k, g in a["grads"].items():
         p = named[k]
         assert p.grad is not None, k
@@ -43,8 +44,11 @@ def _compare(model, a, out, att, loss, tag, rtol=1e-5):
         assert got.shape == g.shape, k
         scale = float(g.abs().max())
         e = float((got - g.double()).abs().max())
-        if scale == 0.0:
-            assert e <= 1e-6, k                   # e.g. AttentionNet's output bias: a shift of all scores cancels in the softmax
+        if scale <= noise:
+            # a gradient that is zero by construction — AttentionNet's output bias: a shift of all scores cancels in the softmax —
+            # comes out of the reference's autograd as fp32 rounding noise (6e-8 in g3_att_train_vec64) and out of the HIP
+            # backward as an exact 0: both must stay inside the noise floor, 1e-8 of the loss
+            assert e <= noise and float(got.abs().max()) <= noise, k
             continue
         worst = max(worst, e / scale)
         assert e <= rtol * scale, f"{k}: max abs err {e:.3e} vs largest reference element {scale:.3e}"
