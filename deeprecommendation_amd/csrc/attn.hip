@@ -12,6 +12,7 @@
 // The tables (pr, feat) are small (catalogue x 64..128 floats) and stay L2 / Infinity-Cache resident; the
 // kernel is bound by gathered cache bandwidth, not by arithmetic.
 #include "ncf_common.h"
+#include "attn_util.h"
 #include <math.h>
 #include <atomic>
 #include <type_traits>
@@ -21,79 +22,6 @@
 #endif
 
 namespace ncf {
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
-// Wave-wide reductions on the VALU (DPP row operations + 4 readlanes) instead of six dependent ds_bpermute round trips:
-// quad swaps, then half-row and row mirrors give every lane its 16-lane row's total; the four row totals are combined
-// from lanes 15 / 31 / 47 / 63.  The result is wave-uniform.  Used by the grouped kernel, whose single wave per SIMD
-// pair cannot hide LDS latency.  (Same pairing for max and sum: the sum's association order is fixed, run to run.)
-template <typename Op>
-__device__ __forceinline__ float wave_reduce_dpp(float v, Op op) {
-    auto dpp = [](float x, auto ctrl) {
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
-    };
-    v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));    // quad_perm [1,0,3,2]
-    v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));    // quad_perm [2,3,0,1]
-    v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror
-    v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror
-    const int b = __float_as_int(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 31));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 63));
-    return op(op(r0, r1), op(r2, r3));
-}
-
-// The same reduction for N values at once: every DPP stage is applied to all of them before the next one, so the N
-// dependency chains interleave in the instruction stream.  Results are wave-uniform.
-template <int N, typename Op>
-__device__ __forceinline__ void wave_reduce_dpp_n(float (&v)[N], Op op) {
-    auto dpp = [](float x, auto ctrl) {
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
-    };
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = op(v[i], dpp(v[i], std::integral_constant<int, 0xB1>{}));
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = op(v[i], dpp(v[i], std::integral_constant<int, 0x4E>{}));
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = op(v[i], dpp(v[i], std::integral_constant<int, 0x141>{}));
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = op(v[i], dpp(v[i], std::integral_constant<int, 0x140>{}));
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int b = __float_as_int(v[i]);
-        const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 31));
-        const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 63));
-        v[i] = op(op(r0, r1), op(r2, r3));
-    }
-}
-
-// e^x for x <= 0 (softmax arguments; x = -inf gives 0): x log2(e) as an exact product hi + lo, 2^hi on the hardware
-// exponential, the low part as a first-order factor — about 2 ulp, 9 instructions, no range reduction (a result below the
-// normal range may flush to 0, which for a softmax term next to a term of 1 is 0 anyway).
-__device__ __forceinline__ float exp_le0(float x) {
-    const float hi = x * 1.44269504088896341f;
-    const float lo = fmaf(x, 1.44269504088896341f, -hi) + x * 1.92596299112661746e-8f;
-    const float r = __builtin_amdgcn_exp2f(hi);
-    return x == -INFINITY ? 0.f : fmaf(r, lo * 0.693147180559945309f, r);
-}
-
-// LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land contiguously from the wave-uniform LDS byte address in M0, each
-// lane fetching from ITS OWN global address).  Inline asm: M0 is saved and restored inside the statement; completion is
-// counted by hand (s_waitcnt vmcnt) before the barrier that precedes the reads.
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
-}
 
 // Training-time dropout of AttentionNet's hidden layer (attention_ncf.py:112-117: Linear, ReLU, Dropout, Linear — one mask element
 // per (pair, rated entry, hidden unit)).  Never stored: element (entry e, units 4c..4c+3) keeps iff a 16-bit slice of a
@@ -1060,7 +988,7 @@ __global__ void group_count_kernel(const int64_t* __restrict__ pair_row, int64_t
 // one workgroup: exclusive scans of counts -> grp_ptr and of ceil(counts / ppw) -> wg_ptr; cursor[r] = grp_ptr[r]
 __global__ __launch_bounds__(1024) void group_scan_kernel(const int* __restrict__ counts, int64_t R, int ppw,
                                                           int64_t* __restrict__ grp_ptr, int64_t* __restrict__ wg_ptr,
-                                                          int* __restrict__ cursor) {
+                                                          int* __restrict__ cursor, int32_t* __restrict__ wg_row) {
     __shared__ int64_t sa[1024], sb[1024];
     __shared__ int64_t carry_a, carry_b;
     if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
@@ -1085,6 +1013,8 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int* __restrict_
             grp_ptr[i] = ea;
             wg_ptr[i] = eb;
             cursor[i] = (int)ea;
+            if (wg_row)
+                for (int64_t w = 0; w < wgs; ++w) wg_row[eb + w] = (int32_t)i;   // workgroup -> row, read instead of a binary search
         }
         __syncthreads();
         if (threadIdx.x == 1023) { carry_a += sa[1023]; carry_b += sb[1023]; }
@@ -1099,7 +1029,7 @@ template <bool LDS_COUNTERS>
 __global__ __launch_bounds__(1024) void group_small_kernel(const int64_t* __restrict__ pair_row, int64_t B, int64_t R, int ppw,
                                                            int* __restrict__ gcounts, int* __restrict__ gcursor, int* __restrict__ bad,
                                                            int64_t* __restrict__ grp_ptr, int64_t* __restrict__ wg_ptr,
-                                                           int64_t* __restrict__ pair_ids) {
+                                                           int64_t* __restrict__ pair_ids, int32_t* __restrict__ wg_row) {
     constexpr int LDS_ROWS = 4096;
     __shared__ int lcounts[LDS_COUNTERS ? LDS_ROWS : 1], lcursor[LDS_COUNTERS ? LDS_ROWS : 1];
     __shared__ int sa[1024], sb[1024];
@@ -1156,8 +1086,11 @@ __global__ __launch_bounds__(1024) void group_small_kernel(const int64_t* __rest
             grp_ptr[i] = ea;
             wg_ptr[i] = eb;
             cursor[i] = ea;
+            const int wgs = (c + ppw - 1) / ppw;
+            if (wg_row)
+                for (int w = 0; w < wgs; ++w) wg_row[eb + w] = (int32_t)i;
             ea += c;
-            eb += (c + ppw - 1) / ppw;
+            eb += wgs;
         }
         __syncthreads();
     }
@@ -1400,7 +1333,14 @@ extern "C" size_t ncf_group_pairs_workspace_bytes(int64_t n_rows) { return (size
 
 extern "C" int ncf_group_pairs(const int64_t* pair_row, int64_t B, int64_t R, int pairs_per_wg, int64_t* grp_ptr, int64_t* pair_ids,
                                int64_t* wg_ptr, void* workspace, size_t workspace_bytes, int32_t* oob, ncf_stream_t stream) {
+    return ncf_group_pairs_rows(pair_row, B, R, pairs_per_wg, grp_ptr, pair_ids, wg_ptr, nullptr, workspace, workspace_bytes, oob, stream);
+}
+
+extern "C" int ncf_group_pairs_rows(const int64_t* pair_row, int64_t B, int64_t R, int pairs_per_wg, int64_t* grp_ptr, int64_t* pair_ids,
+                                    int64_t* wg_ptr, int32_t* wg_row, void* workspace, size_t workspace_bytes, int32_t* oob,
+                                    ncf_stream_t stream) {
     if (B < 0 || R < 0 || pairs_per_wg < 1) return fail(NCF_EINVAL, "ncf_group_pairs: bad sizes");
+    if (R >= (int64_t)1 << 31) return fail(NCF_EUNSUPPORTED, "ncf_group_pairs: more than 2^31 rows");
     if (!grp_ptr || !wg_ptr || (B > 0 && (!pair_row || !pair_ids)) || !workspace) return fail(NCF_EINVAL, "ncf_group_pairs: null pointer");
     if (B >= (int64_t)1 << 31) return fail(NCF_EUNSUPPORTED, "ncf_group_pairs: more than 2^31 pairs");
     if (workspace_bytes < ncf_group_pairs_workspace_bytes(R)) return fail(NCF_EWORKSPACE, "ncf_group_pairs: workspace too small");
@@ -1409,13 +1349,13 @@ extern "C" int ncf_group_pairs(const int64_t* pair_row, int64_t B, int64_t R, in
     int* cursor = counts + R;
     int* bad = oob ? oob : cursor + R;                     // the spare word of the workspace when the caller passes no flag
     if (B <= 32768 && R <= 32768) {
-        if (R <= 4096) hipLaunchKernelGGL(group_small_kernel<true>, dim3(1), dim3(1024), 0, s, pair_row, B, R, pairs_per_wg, counts, cursor, bad, grp_ptr, wg_ptr, pair_ids);
-        else hipLaunchKernelGGL(group_small_kernel<false>, dim3(1), dim3(1024), 0, s, pair_row, B, R, pairs_per_wg, counts, cursor, bad, grp_ptr, wg_ptr, pair_ids);
+        if (R <= 4096) hipLaunchKernelGGL(group_small_kernel<true>, dim3(1), dim3(1024), 0, s, pair_row, B, R, pairs_per_wg, counts, cursor, bad, grp_ptr, wg_ptr, pair_ids, wg_row);
+        else hipLaunchKernelGGL(group_small_kernel<false>, dim3(1), dim3(1024), 0, s, pair_row, B, R, pairs_per_wg, counts, cursor, bad, grp_ptr, wg_ptr, pair_ids, wg_row);
         return check_launch("ncf_group_pairs");
     }
     if (hipMemsetAsync(workspace, 0, ncf_group_pairs_workspace_bytes(R), s) != hipSuccess) return check_launch("ncf_group_pairs(memset)");
     if (B > 0) hipLaunchKernelGGL(group_count_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, pair_row, B, R, counts, bad);
-    hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, s, counts, R, pairs_per_wg, grp_ptr, wg_ptr, cursor);
+    hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, s, counts, R, pairs_per_wg, grp_ptr, wg_ptr, cursor, wg_row);
     if (B > 0) hipLaunchKernelGGL(group_scatter_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, pair_row, B, R, cursor, pair_ids);
     return check_launch("ncf_group_pairs");
 }

@@ -62,6 +62,12 @@ SIGNATURES = {
                                           _c_i64, _c_p, _c_p, _c_p]),
     "ncf_group_pairs_workspace_bytes": (_c_size, [_c_i64]),
     "ncf_group_pairs": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
+    "ncf_group_pairs_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
+    "ncf_attn_split_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
+    "ncf_attn_split_workspace_bytes": (_c_size, [_c_i64, _c_int, _c_int]),
+    "ncf_attn_forward_split": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
+                                        _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_int, _c_p, _c_p,
+                                        _c_i64, _c_int, _c_p, _c_size, _c_p]),
     "ncf_edge_softmax_csr": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_score_folded_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "ncf_score_folded": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p,
@@ -577,21 +583,52 @@ def group_pairs(pair_row: torch.Tensor, n_rows: int, pairs_per_wg: int):
     grp_ptr = torch.empty(R + 1, dtype=torch.int64, device=dev)
     wg_ptr = torch.empty(R + 1, dtype=torch.int64, device=dev)
     pair_ids = torch.empty(max(B, 1), dtype=torch.int64, device=dev)
+    # workgroup -> CSR row (the grid bound of the grouped kernels: every non-empty row adds at most one partly filled workgroup)
+    wg_row = torch.empty((B + int(pairs_per_wg) - 1) // int(pairs_per_wg) + min(R, B) + 1, dtype=torch.int32, device=dev)
     nbytes = lib.ncf_group_pairs_workspace_bytes(R)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    _check(lib.ncf_group_pairs(_ptr(pair_row), B, R, int(pairs_per_wg), _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr), _ptr(ws), nbytes,
-                               _ptr(_oob_flag(dev)), _stream(pair_row)))
-    return grp_ptr, pair_ids[:B], wg_ptr
+    _check(lib.ncf_group_pairs_rows(_ptr(pair_row), B, R, int(pairs_per_wg), _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr), _ptr(wg_row),
+                                    _ptr(ws), nbytes, _ptr(_oob_flag(dev)), _stream(pair_row)))
+    return Grouping(grp_ptr, pair_ids[:B], wg_ptr, wg_row)
+
+
+class Grouping(tuple):
+    """(grp_ptr, pair_ids, wg_ptr) of ncf_group_pairs — unpacks as that triple — plus ``wg_row`` (workgroup -> CSR row)."""
+
+    def __new__(cls, grp_ptr, pair_ids, wg_ptr, wg_row=None):
+        self = super().__new__(cls, (grp_ptr, pair_ids, wg_ptr))
+        self.wg_row = wg_row
+        return self
+
+
+def attn_split_supported(mode: int, A: int, Fdim: int, pairs_per_wg: int) -> bool:
+    return bool(load_library().ncf_attn_split_supported(int(mode), int(A), int(Fdim), int(pairs_per_wg)))
+
+
+def default_attn_nsplit(B: int, n_rows: int, nnz: int, pairs_per_wg: int) -> int:
+    """Slices of a rated set for the entry-split attention kernel, from sizes the host already holds (no device read): enough
+    (group, slice) workgroups to give every CU two, at most one slice per 64-entry tile of an average row, at most 8."""
+    if B <= 0 or n_rows <= 0:
+        return 1
+    groups = (B + pairs_per_wg - 1) // pairs_per_wg + min(n_rows, B) // 2          # between the bound and its half
+    tiles = max(1, (nnz // max(n_rows, 1) + 63) // 64)
+    want = (2 * num_cus() + groups - 1) // groups
+    return int(max(1, min(want, tiles, 8)))
+
+
+def num_cus() -> int:
+    return 256
 
 
 def attn_forward_grouped(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[torch.Tensor], b1: float,
                          rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, pair_row: torch.Tensor,
                          feat: torch.Tensor, out_bias: Optional[torch.Tensor] = None, pairs_per_wg: Optional[int] = None,
-                         grouping=None, return_weights: bool = False):
+                         grouping=None, return_weights: bool = False, nsplit: Optional[int] = None):
     """LDS-tiled attention for pairs that share rated sets: CSR row ``pair_row[b]`` is pair b's set.  Returns out_feat
     (B, Fdim), or (out_feat, weights) with ``return_weights``: the attention weights in the layout of the expanded
     per-pair CSR (``SparseRatings.expanded()``).  ``grouping`` = (group_pairs(pair_row, R, ppw), ppw) computed earlier
-    for this batch skips the sort."""
+    for this batch skips the sort.  Where ncf_attn_split_supported() holds (and no weights are asked for) the call takes the
+    entry-split form (``nsplit`` slices of each rated set; default from the batch's sizes; 1 = one workgroup per group)."""
     lib = load_library()
     _dev(pc, "pc")
     B, A, ldpc = _rows2d(pc, "pc")
@@ -605,12 +642,25 @@ def attn_forward_grouped(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Opti
         raise ValueError("pair_row must name one CSR row per pair")
     R = rowptr.numel() - 1
     if grouping is not None:
-        (grp_ptr, pair_ids, wg_ptr), pairs_per_wg = grouping
+        grp, pairs_per_wg = grouping
     else:
         if pairs_per_wg is None:
             pairs_per_wg = default_pairs_per_wg(B)
-        grp_ptr, pair_ids, wg_ptr = group_pairs(pair_row.to(torch.int64).contiguous(), R, pairs_per_wg)
+        grp = group_pairs(pair_row.to(torch.int64).contiguous(), R, pairs_per_wg)
+    grp_ptr, pair_ids, wg_ptr = grp
     out = torch.empty((B, Fdim), dtype=torch.float32, device=pc.device)
+    wg_row = getattr(grp, "wg_row", None)
+    if (not return_weights and get_option("attn_grouped_kernel") == 0
+            and lib.ncf_attn_split_supported(mode, A, Fdim, int(pairs_per_wg)) and I > 0):
+        # entry-split form (round 3): (group of pairs) x (slice of the rated set) workgroups + a merge of the softmax partials
+        ns = int(nsplit) if nsplit is not None else default_attn_nsplit(B, R, col.numel(), int(pairs_per_wg))
+        nbytes = lib.ncf_attn_split_workspace_bytes(B, Fdim, ns)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=pc.device) if ns > 1 else None
+        _check(lib.ncf_attn_forward_split(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), float(b1), _ptr(rowptr), _ptr(col),
+                                          _ptr(val), R, I, _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr), _ptr(wg_row), B,
+                                          int(pairs_per_wg), _ptr(feat), ldf, Fdim, _ptr(out_bias), _ptr(out), out.stride(0),
+                                          ns, _ptr(ws), nbytes, _stream(pc)))
+        return out
     wts = wts_off = None
     if return_weights:
         lens = (rowptr[1:] - rowptr[:-1])[pair_row.to(torch.int64)]

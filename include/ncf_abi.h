@@ -333,6 +333,33 @@ int ncf_group_pairs(const int64_t* dev_pair_row, int64_t B, int64_t n_rows, int 
                     int64_t* dev_grp_ptr, int64_t* dev_pair_ids, int64_t* dev_wg_ptr,
                     void* dev_workspace, size_t workspace_bytes, int32_t* dev_oob_flag, ncf_stream_t stream);
 
+/* ncf_group_pairs that also writes dev_wg_row[w] = CSR row of workgroup w (int32, ceil(B / pairs_per_wg) + min(n_rows, B) slots —
+ * the grid bound of the grouped kernels): ncf_attn_forward_split reads it instead of searching dev_wg_ptr. */
+int ncf_group_pairs_rows(const int64_t* dev_pair_row, int64_t B, int64_t n_rows, int pairs_per_wg,
+                         int64_t* dev_grp_ptr, int64_t* dev_pair_ids, int64_t* dev_wg_ptr, int32_t* dev_wg_row,
+                         void* dev_workspace, size_t workspace_bytes, int32_t* dev_oob_flag, ncf_stream_t stream);
+
+/* Entry-split form of ncf_attn_forward_grouped (same operands and result; attention weights are not available here):
+ * the rated set of a row is cut into `nsplit` slices of whole 64-entry tiles, one workgroup per (group of pairs, slice)
+ * leaves a softmax partial (running maximum, sum, un-normalised aggregate) in dev_workspace and a second kernel of the same
+ * call merges them in slice order (deterministic).  Replaces the same reference lines as ncf_attn_forward_grouped
+ * (models/attention_ncf.py:154-216); it exists because a batch of a few thousand pairs is too few workgroups of too long
+ * a chain for the one-workgroup-per-group form.  nsplit = 1 needs no workspace and launches one kernel.
+ * Shapes: ncf_attn_split_supported() (A % 32 == 0, A <= 256, Fdim 64 or 128, MLP / cosine modes); else NCF_EUNSUPPORTED.
+ * dev_wg_row may be NULL (binary search over dev_wg_ptr). */
+int ncf_attn_split_supported(int mode, int A, int Fdim, int pairs_per_wg);
+size_t ncf_attn_split_workspace_bytes(int64_t B, int Fdim, int nsplit);
+int ncf_attn_forward_split(int mode,
+                           const float* dev_pc, int64_t ldpc, const float* dev_pr, int64_t ldpr, int A,
+                           const float* dev_w1, float b1,
+                           const int64_t* dev_rowptr, const int32_t* dev_col, const float* dev_val,
+                           int64_t n_rows, int64_t n_rated,
+                           const int64_t* dev_grp_ptr, const int64_t* dev_pair_ids, const int64_t* dev_wg_ptr,
+                           const int32_t* dev_wg_row, int64_t B, int pairs_per_wg,
+                           const float* dev_feat, int64_t ldfeat, int Fdim, const float* dev_out_bias,
+                           float* dev_out_feat, int64_t ldout,
+                           int nsplit, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
+
 /* out[r, :] = x[r, :] / max(||x[r, :]||_2, 1e-12) — torch.nn.functional.normalize(p=2, dim=1) of the cosine
  * variant, models/attention_ncf.py:167-168. */
 int ncf_l2_normalize_rows(const float* dev_x, int64_t ldx, int64_t R, int E, float* dev_out, int64_t ldout,

@@ -436,3 +436,60 @@ def test_cfg3_bench_workload_full_size_grouped_kernel(gpu):
     um2.scatter_(1, torch.searchsorted(ids2, cols2), r2.val.view(B, nnz)[rows2])
     state2 = {k: v.detach().cpu() for k, v in model2.state_dict().items()}
     assert_close(out2[sl2], O.attention_ncf_forward(state2, cand2[sl2].cpu(), catalogue2[ids2].cpu(), um2.cpu()))
+
+
+@pytest.mark.parametrize("mode_name", ["mlp", "mlp_scaled", "cos"])
+@pytest.mark.parametrize("A,Fdim", [(128, 64), (32, 64), (64, 128), (256, 128)])
+@pytest.mark.parametrize("ppw,nsplit", [(32, 1), (32, 4), (16, 2), (32, 3), (5, 8)])
+def test_entry_split_kernel_vs_per_pair(gpu, mode_name, A, Fdim, ppw, nsplit):
+    """ncf_attn_forward_split (round 3: (group of pairs) x (slice of the rated set) workgroups + merge of the softmax partials)
+    against the per-pair kernel on the same batch: rows of 0, 1, 63, 64, 65, 300 entries (empty slices, ragged last tiles, more
+    slices than tiles), users with one pair and with many, a group size that is not a multiple of 4.  1e-5; bitwise repeatable."""
+    from deeprecommendation_amd import native
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import SparseRatings
+    g = torch.Generator(device=gpu).manual_seed(A * 7 + Fdim + ppw + nsplit)
+    I, B = 700, 333
+    lens = torch.tensor([0, 1, 63, 64, 65, 300, 129, 7, 256, 2], device=gpu)
+    R = lens.numel()
+    rowptr = torch.zeros(R + 1, dtype=torch.int64, device=gpu)
+    rowptr[1:] = torch.cumsum(lens, 0)
+    col = torch.cat([torch.randperm(I, device=gpu, generator=g)[:int(n)].sort().values for n in lens.tolist()]).to(torch.int32)
+    val = torch.randint(1, 11, (col.numel(),), device=gpu, generator=g).float() * 0.5 - 2.9
+    who = torch.randint(0, R, (B,), device=gpu, generator=g)
+    who[:3] = torch.tensor([0, 1, 5], device=gpu)
+    mode = {"mlp": native.ATT_MLP, "mlp_scaled": native.ATT_MLP_SCALED, "cos": native.ATT_COS}[mode_name]
+    f = 2.0 ** -native.ATT_SCALE_LOG2 if mode_name == "mlp_scaled" else 1.0
+    pr = torch.randn(I, A, device=gpu, generator=g) * 0.3 * f
+    pc = torch.randn(B, A, device=gpu, generator=g) * 0.3 * f
+    feat = torch.randn(I, Fdim, device=gpu, generator=g)
+    w1 = None if mode_name == "cos" else torch.randn(A, device=gpu, generator=g) * 0.2 / f
+    bias = torch.randn(Fdim, device=gpu, generator=g)
+    assert native.attn_split_supported(mode, A, Fdim, ppw)
+    ex = SparseRatings(rowptr, col, val, I, pair_row=who).expanded()
+    ref, _ = native.attn_forward(mode, pc, pr, w1, 0.1, ex.rowptr, ex.col, ex.val, feat, out_bias=bias)
+    out = native.attn_forward_grouped(mode, pc, pr, w1, 0.1, rowptr, col, val, who, feat, out_bias=bias, pairs_per_wg=ppw, nsplit=nsplit)
+    assert_close(out, ref)
+    empty = who == 0
+    assert torch.equal(out[empty], bias.expand(int(empty.sum()), Fdim))          # no rated entry: weights 0, the bias alone (:208-209)
+    out2 = native.attn_forward_grouped(mode, pc, pr, w1, 0.1, rowptr, col, val, who, feat, out_bias=bias, pairs_per_wg=ppw, nsplit=nsplit)
+    assert torch.equal(out, out2)
+
+
+def test_entry_split_kernel_out_of_catalogue_columns_and_default_nsplit(gpu):
+    from deeprecommendation_amd import native
+    g = torch.Generator(device=gpu).manual_seed(3)
+    I, B, A, Fdim, R, nnz = 500, 2048, 128, 64, 16, 200
+    rowptr = torch.arange(0, (R + 1) * nnz, nnz, device=gpu, dtype=torch.int64)
+    col = torch.stack([torch.randperm(I, device=gpu, generator=g)[:nnz].sort().values for _ in range(R)]).reshape(-1).to(torch.int32)
+    col[5] = -1            # columns outside the catalogue are ignored (weight 0), like the per-pair kernel
+    col[nnz + 9] = I + 3
+    val = torch.randn(R * nnz, device=gpu, generator=g)
+    who = torch.randint(0, R, (B,), device=gpu, generator=g)
+    pr, pc = torch.randn(I, A, device=gpu, generator=g) * 0.3, torch.randn(B, A, device=gpu, generator=g) * 0.3
+    feat, w1 = torch.randn(I, Fdim, device=gpu, generator=g), torch.randn(A, device=gpu, generator=g) * 0.2
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import SparseRatings
+    ex = SparseRatings(rowptr, col, val, I, pair_row=who).expanded()
+    ref, _ = native.attn_forward(native.ATT_MLP, pc, pr, w1, -0.2, ex.rowptr, ex.col, ex.val, feat)
+    assert native.default_attn_nsplit(B, R, col.numel(), native.default_pairs_per_wg(B)) > 1
+    out = native.attn_forward_grouped(native.ATT_MLP, pc, pr, w1, -0.2, rowptr, col, val, who, feat)       # default ppw / nsplit
+    assert_close(out, ref)
