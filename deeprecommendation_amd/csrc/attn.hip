@@ -13,6 +13,7 @@
 // kernel is bound by gathered cache bandwidth, not by arithmetic.
 #include "ncf_common.h"
 #include "attn_util.h"
+#include "group_pairs.h"
 #include <math.h>
 #include <atomic>
 #include <type_traits>
@@ -949,34 +950,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_grouped_sc_kernel(const float
 
 // ---- pairs listed row by row for the grouped kernel (a counting sort; order inside a row is irrelevant: every pair's
 // output is computed independently) ----
-// Wave-aggregated atomics: the lanes of a wave that target the same row elect a leader which adds their count once and
-// hands every lane its rank.  One user scored against a whole catalogue (the web backend's call: 65 536 pairs, ONE row)
-// otherwise serialises 65 536 atomics on a single counter in each pass (~0.65 ms each, measured 2.0 ms per request).
-// Returns the value the lane's own atomicAdd(&counter[r], 1) would have returned in SOME valid order; inactive lanes
-// (valid == false) take no part.
-__device__ __forceinline__ int wave_aggregated_inc(int* __restrict__ counter, int64_t r, bool valid) {
-    int result = 0;
-    bool pending = valid;
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {               // two rounds take the one or two hot rows of a wave ...
-        const unsigned long long todo = __ballot(pending);
-        if (todo == 0) break;
-        const int leader = __ffsll((long long)todo) - 1;
-        const int64_t r0 = __shfl(r, leader, 64);
-        const unsigned long long same = __ballot(pending && r == r0);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&counter[r0], __popcll(same));
-        base = __shfl(base, leader, 64);
-        if (pending && r == r0) {
-            result = base + __popcll(same & ((1ull << lane) - 1ull));
-            pending = false;
-        }
-    }
-    if (pending) result = atomicAdd(&counter[r], 1);        // ... lanes on other rows add in parallel as before
-    return result;
-}
-
 __global__ void group_count_kernel(const int64_t* __restrict__ pair_row, int64_t B, int64_t R, int* __restrict__ counts,
                                    int* __restrict__ bad) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1022,86 +995,13 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int* __restrict_
     }
     if (threadIdx.x == 0) { grp_ptr[R] = carry_a; wg_ptr[R] = carry_b; }
 }
-// the three steps in ONE 1024-thread workgroup for small batches (an evaluation batch is a few thousand pairs: three
-// launches and a memset cost more than the work).  Counters and cursors live in LDS when the rows fit (LDS atomics: a
-// batch of 4096 pairs over 64 users puts 64 increments on each counter — 20 us with global atomics, 4 with LDS ones).
 template <bool LDS_COUNTERS>
 __global__ __launch_bounds__(1024) void group_small_kernel(const int64_t* __restrict__ pair_row, int64_t B, int64_t R, int ppw,
                                                            int* __restrict__ gcounts, int* __restrict__ gcursor, int* __restrict__ bad,
                                                            int64_t* __restrict__ grp_ptr, int64_t* __restrict__ wg_ptr,
                                                            int64_t* __restrict__ pair_ids, int32_t* __restrict__ wg_row) {
-    constexpr int LDS_ROWS = 4096;
-    __shared__ int lcounts[LDS_COUNTERS ? LDS_ROWS : 1], lcursor[LDS_COUNTERS ? LDS_ROWS : 1];
-    __shared__ int sa[1024], sb[1024];
-    __shared__ int carry_a, carry_b;
-    int* counts = LDS_COUNTERS ? lcounts : gcounts;
-    int* cursor = LDS_COUNTERS ? lcursor : gcursor;
-    for (int64_t i = threadIdx.x; i < R; i += 1024) counts[i] = 0;
-    if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
-    __syncthreads();
-    for (int64_t base = 0; base < B; base += 1024) {       // uniform trip count: the aggregated atomic is a wave-level operation
-        const int64_t b = base + threadIdx.x;
-        const int64_t r = b < B ? pair_row[b] : -1;
-        const bool ok = b < B && r >= 0 && r < R;
-        if (b < B && !ok) *bad = 1;
-        (void)wave_aggregated_inc(counts, r, ok);
-    }
-    __syncthreads();
-    // Exclusive scans of the row counts and of the per-row workgroup counts (B <= 32768: the sums fit 32 bits).  Each
-    // thread owns a contiguous run of rows: serial sums over its run, ONE block scan of the 1024 run totals (wave scans by
-    // shuffles + a scan of the 16 wave totals: three barriers whatever R is — the blockwise Hillis-Steele scan this
-    // replaces spent ~23 barriers per 1024 rows, 14 of the kernel's 20 us at R = 4096), then the run is written out.
-    {
-        const int per = (int)((R + 1023) / 1024);
-        const int64_t lo = (int64_t)threadIdx.x * per;
-        const int64_t hi = lo + per < R ? lo + per : R;
-        int ta = 0, tb = 0;
-        for (int64_t i = lo; i < hi; ++i) {
-            const int c = counts[i];
-            ta += c;
-            tb += (c + ppw - 1) / ppw;
-        }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        int ia = ta, ib = tb;                                   // inclusive scan inside the wave
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int ua = __shfl_up(ia, off, 64), ub = __shfl_up(ib, off, 64);
-            if (lane >= off) { ia += ua; ib += ub; }
-        }
-        if (lane == 63) { sa[wave] = ia; sb[wave] = ib; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int ca = 0, cb = 0;
-            for (int w = 0; w < 16; ++w) {                      // exclusive scan of the 16 wave totals
-                const int va = sa[w], vb = sb[w];
-                sa[w] = ca; sb[w] = cb;
-                ca += va; cb += vb;
-            }
-            carry_a = ca; carry_b = cb;
-        }
-        __syncthreads();
-        int ea = sa[wave] + ia - ta, eb = sb[wave] + ib - tb;   // exclusive prefix of this thread's run
-        for (int64_t i = lo; i < hi; ++i) {
-            const int c = counts[i];
-            grp_ptr[i] = ea;
-            wg_ptr[i] = eb;
-            cursor[i] = ea;
-            const int wgs = (c + ppw - 1) / ppw;
-            if (wg_row)
-                for (int w = 0; w < wgs; ++w) wg_row[eb + w] = (int32_t)i;
-            ea += c;
-            eb += wgs;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { grp_ptr[R] = carry_a; wg_ptr[R] = carry_b; }
-    for (int64_t base = 0; base < B; base += 1024) {
-        const int64_t b = base + threadIdx.x;
-        const int64_t r = b < B ? pair_row[b] : -1;
-        const bool ok = b < B && r >= 0 && r < R;
-        const int slot = wave_aggregated_inc(cursor, r, ok);
-        if (ok) pair_ids[slot] = b;
-    }
+    __shared__ int lds[group_small_lds_ints<LDS_COUNTERS>(1024)];
+    group_small_body<LDS_COUNTERS, 1024>(pair_row, B, R, ppw, gcounts, gcursor, bad, grp_ptr, wg_ptr, pair_ids, wg_row, lds);
 }
 __global__ void group_scatter_kernel(const int64_t* __restrict__ pair_row, int64_t B, int64_t R, int* __restrict__ cursor,
                                      int64_t* __restrict__ pair_ids) {

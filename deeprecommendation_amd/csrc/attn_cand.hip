@@ -1,0 +1,244 @@
+// K2c — the candidate side of an AttentionNCF forward in ONE launch (models/attention_ncf.py:150 and the candidate half of
+// AttentionNet.0, :176-179), fp32, gfx950:
+//     cand_emb = x . Wi^T + bi            (B, K) x (N1, K)^T     K = item_dim (2094 in the reference's data), N1 = item_emb
+//     pc       = cand_emb . Wc^T + b0     (B, N1) x (N2, N1)^T   N2 = att_dense, Wc = AttentionNet.0.weight[:, :N1]
+// and, in a spare workgroup, the grouping of the batch's pairs by rated set (ncf_group_pairs: it depends on pair_row only).
+// Round 2 ran these as three launches — a skinny split-K Linear (21.6 us: one 32-column block per workgroup, so x was read twice and
+// every wave waited a full HBM round trip per 32-wide K block), a 12 us Linear for 67 MFLOP, an 8 us single-workgroup counting sort.
+//
+// One workgroup = 16 rows of x and ALL N1 columns (x is read once; B = 4096 gives 256 workgroups, one per CU), 8 waves = 8 K slices.
+// A wave streams its slice in 32-wide blocks: global -> registers (eight lanes per row: whole 128-byte runs; rows of K floats are
+// only 4-byte aligned) TWO blocks ahead, registers -> its own LDS staging area (16-byte slot s of row r at s ^ ((r >> 1) & 7)),
+// LDS -> MFMA operands (v_mfma_f32_16x16x4_f32: exact fp32 fmaf chains; lane (i, g) holds k = 16h + 4g + j of row i for step (h, j):
+// the same k pairing for x and W, so only the summation order inside a block is permuted).  No barrier in the loop: a wave reads
+// only what it wrote.  The 8 partial tiles are added through LDS in slice order (deterministic), the 16 x N1 cand_emb tile stays in
+// LDS and feeds the second product (N2 / 16 column tiles over the waves, Wc from L2).
+#include "ncf_common.h"
+#include "group_pairs.h"
+#include <atomic>
+
+namespace ncf {
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // rows of x / Wi may be only 4-byte aligned
+
+struct CandArgs {
+    const float* x; const float* Wi; const float* bi; const float* Wc; const float* b0;
+    float* emb; float* pc;
+    int64_t B, ldx, ldw, ldemb, ldpc;
+    int K, N2;
+    // grouping (pair_row == nullptr: none)
+    const int64_t* pair_row; int64_t R; int ppw;
+    int* gcounts; int* gcursor; int* bad; int64_t* grp_ptr; int64_t* wg_ptr; int64_t* pair_ids; int32_t* wg_row;
+};
+
+template <int N1>
+__global__ __launch_bounds__(512, 2) void attn_cand_kernel(const CandArgs a) {
+    constexpr int NWV = 8, TM = 16, NT = N1 / 16, WC = N1 / 8;     // column tiles; W load instructions per block
+    constexpr int STW = (TM + N1) * 32;                            // floats of one wave's staging area
+    constexpr int CES = N1 + 4;                                    // row stride of the cand_emb tile (bank spread)
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool grouping = a.pair_row != nullptr;
+    if (grouping && blockIdx.x == 0) {                             // the spare workgroup: dispatched first, done long before the rest
+        int* lds = reinterpret_cast<int*>(smem_f);
+        __builtin_amdgcn_s_setprio(3);                             // it shares its CU with a tile of the product: let it go first
+        if (a.R <= kGroupLdsRows)
+            group_small_body<true, 512>(a.pair_row, a.B, a.R, a.ppw, a.gcounts, a.gcursor, a.bad, a.grp_ptr, a.wg_ptr, a.pair_ids, a.wg_row, lds);
+        else
+            group_small_body<false, 512>(a.pair_row, a.B, a.R, a.ppw, a.gcounts, a.gcursor, a.bad, a.grp_ptr, a.wg_ptr, a.pair_ids, a.wg_row, lds);
+        return;
+    }
+    const int64_t row0 = ((int64_t)blockIdx.x - (grouping ? 1 : 0)) * TM;
+    if (row0 >= a.B) return;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int lr = lane >> 3, ls = lane & 7;
+    float* const stA = smem_f + (size_t)wave * STW;
+    float* const stW = stA + TM * 32;
+    const int K = a.K;
+    const int NBF = K / 32;                                        // whole 32-wide blocks, split over the waves
+    const int blo = (int)((int64_t)wave * NBF / NWV), bhi = (int)((int64_t)(wave + 1) * NBF / NWV);
+
+    const float* ga[2];
+    const float* gw[WC];
+    unsigned woA[2], woW[WC];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int r = 8 * c + lr;
+        const int64_t m = row0 + r < a.B ? row0 + r : a.B - 1;
+        ga[c] = a.x + m * a.ldx + 4 * ls;
+        woA[c] = r * 32 + ((ls ^ ((r >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int c = 0; c < WC; ++c) {
+        const int r = 8 * c + lr;
+        gw[c] = a.Wi + (int64_t)r * a.ldw + 4 * ls;
+        woW[c] = r * 32 + ((ls ^ ((r >> 1) & 7)) << 2);
+    }
+    unsigned ro[2];                                                // operand reads: chunk g4 + 4h of row i16 (+ 16 nt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) ro[h] = i16 * 32 + ((((g4 + 4 * h) ^ ((i16 >> 1) & 7)) & 7) << 2);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto gload = [&](f32x4 (&va)[2], f32x4 (&vw)[WC], int b) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) va[c] = *reinterpret_cast<const f32x4u*>(ga[c] + 32 * b);
+#pragma unroll
+        for (int c = 0; c < WC; ++c) vw[c] = *reinterpret_cast<const f32x4u*>(gw[c] + 32 * b);
+    };
+    auto stage = [&](const f32x4 (&va)[2], const f32x4 (&vw)[WC]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4*>(stA + woA[c]) = va[c];
+#pragma unroll
+        for (int c = 0; c < WC; ++c) *reinterpret_cast<f32x4*>(stW + woW[c]) = vw[c];
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(stA + ro[h]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(stW + nt * 16 * 32 + ro[h]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc[nt], 0, 0, 0);
+            }
+        }
+    };
+    if (bhi > blo) {
+        f32x4 va0[2], vw0[WC], va1[2], vw1[WC];
+        const int last = bhi - 1;
+        gload(va0, vw0, blo);
+        gload(va1, vw1, blo + 1 < bhi ? blo + 1 : last);
+        for (int b = blo; b < bhi; b += 2) {                       // two blocks in flight in registers; a step's LDS traffic is its own
+            stage(va0, vw0);
+            gload(va0, vw0, b + 2 < bhi ? b + 2 : last);           // past the slice: the last block again (harmless, no branch)
+            compute();
+            if (b + 1 < bhi) {
+                stage(va1, vw1);
+                gload(va1, vw1, b + 3 < bhi ? b + 3 : last);
+                compute();
+            }
+        }
+    }
+    if (wave == 0 && (K & 31)) {                                   // ragged end of K: guarded scalar loads, zero fill (one block, one wave)
+        const int k0 = 32 * NBF + 4 * ls;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = k0 + j < K ? ga[c][32 * NBF + j] : 0.f;
+            *reinterpret_cast<f32x4*>(stA + woA[c]) = v;
+        }
+#pragma unroll
+        for (int c = 0; c < WC; ++c) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = k0 + j < K ? gw[c][32 * NBF + j] : 0.f;
+            *reinterpret_cast<f32x4*>(stW + woW[c]) = v;
+        }
+        compute();
+    }
+    // ---- the 8 K-slices added in slice order ----
+    __syncthreads();                                               // every wave is done with its staging area
+    float* const red = smem_f;                                     // [NWV][TM][N1]
+    float* const ce = smem_f + NWV * TM * N1;                      // [TM][CES]  the cand_emb tile
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(wave * TM + 4 * g4 + i) * N1 + 16 * nt + i16] = acc[nt][i];
+    __syncthreads();
+    for (int o = tid; o < TM * N1; o += 512) {
+        const int r = o / N1, c = o - r * N1;
+        float v = red[o];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) v += red[w * TM * N1 + o];
+        v += a.bi ? a.bi[c] : 0.f;
+        ce[r * CES + c] = v;
+        if (row0 + r < a.B) a.emb[(row0 + r) * a.ldemb + c] = v;
+    }
+    __syncthreads();
+    // ---- pc tile = cand_emb tile . Wc^T + b0 ----
+    for (int ct = wave; ct < a.N2 / 16; ct += NWV) {
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+        const float* wrow = a.Wc + (int64_t)(16 * ct + i16) * N1 + 4 * g4;
+#pragma unroll
+        for (int kk = 0; kk < N1 / 16; ++kk) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ce + i16 * CES + 16 * kk + 4 * g4);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 16 * kk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc2, 0, 0, 0);
+        }
+        const float bv = a.b0 ? a.b0[16 * ct + i16] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = row0 + 4 * g4 + i;
+            if (m < a.B) a.pc[m * a.ldpc + 16 * ct + i16] = acc2[i] + bv;
+        }
+    }
+}
+
+}  // namespace ncf
+
+using namespace ncf;
+
+extern "C" int ncf_attn_candidates_supported(int K, int N1, int N2) {
+    return K >= 1 && (N1 == 64 || N1 == 128) && N2 >= 16 && N2 % 16 == 0 && N2 <= 256;
+}
+
+extern "C" size_t ncf_attn_candidates_workspace_bytes(int64_t n_rows) { return (size_t)(2 * (n_rows > 0 ? n_rows : 0) + 1) * sizeof(int); }
+
+extern "C" int ncf_attn_candidates(const float* x, int64_t B, int64_t ldx, int K, const float* Wi, int64_t ldw, const float* bi, int N1,
+                                   const float* Wc, const float* b0, int N2, float* emb, int64_t ldemb, float* pc, int64_t ldpc,
+                                   const int64_t* pair_row, int64_t R, int pairs_per_wg, int64_t* grp_ptr, int64_t* pair_ids,
+                                   int64_t* wg_ptr, int32_t* wg_row, void* workspace, size_t workspace_bytes, int32_t* oob,
+                                   ncf_stream_t stream) {
+    if (!ncf_attn_candidates_supported(K, N1, N2))
+        return fail(NCF_EUNSUPPORTED, "ncf_attn_candidates: needs item_emb 64 or 128 and att_dense %% 16 == 0, <= 256 (N1 = %d, N2 = %d)", N1, N2);
+    if (B < 0 || ldx < K || ldw < K || ldemb < N1 || ldpc < N2) return fail(NCF_EINVAL, "ncf_attn_candidates: bad sizes");
+    if (B == 0) return NCF_OK;
+    if (!x || !Wi || !Wc || !emb || !pc) return fail(NCF_EINVAL, "ncf_attn_candidates: null pointer");
+    if (!aligned16(Wc)) return fail(NCF_EINVAL, "ncf_attn_candidates: Wc must be 16-byte aligned (contiguous (N2, N1))");
+    CandArgs a{};
+    a.x = x; a.Wi = Wi; a.bi = bi; a.Wc = Wc; a.b0 = b0; a.emb = emb; a.pc = pc;
+    a.B = B; a.ldx = ldx; a.ldw = ldw; a.ldemb = ldemb; a.ldpc = ldpc; a.K = K; a.N2 = N2;
+    if (pair_row) {
+        if (R < 0 || pairs_per_wg < 1 || B > 32768 || R > 32768)
+            return fail(NCF_EUNSUPPORTED, "ncf_attn_candidates: the fused grouping takes B, n_rows <= 32768 (use ncf_group_pairs_rows)");
+        if (!grp_ptr || !pair_ids || !wg_ptr || !workspace) return fail(NCF_EINVAL, "ncf_attn_candidates: null grouping pointer");
+        if (workspace_bytes < ncf_attn_candidates_workspace_bytes(R)) return fail(NCF_EWORKSPACE, "ncf_attn_candidates: workspace too small");
+        a.pair_row = pair_row; a.R = R; a.ppw = pairs_per_wg;
+        a.gcounts = (int*)workspace; a.gcursor = a.gcounts + R;
+        a.bad = oob ? oob : a.gcursor + R;
+        a.grp_ptr = grp_ptr; a.wg_ptr = wg_ptr; a.pair_ids = pair_ids; a.wg_row = wg_row;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((B + 15) / 16) + (pair_row ? 1u : 0u);
+    size_t lds = (size_t)8 * (16 + N1) * 32 * 4;                    // staging; the reduction (8 x 16 x N1) + the tile fit inside it
+    const size_t lds_red = ((size_t)8 * 16 * N1 + 16 * (N1 + 4)) * 4;
+    const size_t lds_grp = (size_t)group_small_lds_ints<true>(512) * sizeof(int);
+    if (lds_red > lds) lds = lds_red;
+    if (pair_row && lds_grp > lds) lds = lds_grp;
+    auto raise = [&](const void* fn, std::atomic<unsigned long long>& done) -> bool {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (done.load(std::memory_order_relaxed) >> dev & 1ull) return true;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        done.fetch_or(1ull << dev, std::memory_order_relaxed);
+        return true;
+    };
+    if (N1 == 64) {
+        static std::atomic<unsigned long long> done{0};
+        if (!raise((const void*)attn_cand_kernel<64>, done)) return fail(NCF_EUNSUPPORTED, "ncf_attn_candidates: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL((attn_cand_kernel<64>), dim3(blocks), dim3(512), lds, s, a);
+    } else {
+        static std::atomic<unsigned long long> done{0};
+        if (!raise((const void*)attn_cand_kernel<128>, done)) return fail(NCF_EUNSUPPORTED, "ncf_attn_candidates: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL((attn_cand_kernel<128>), dim3(blocks), dim3(512), lds, s, a);
+    }
+    return check_launch("ncf_attn_candidates");
+}

@@ -25,6 +25,9 @@
 #include <atomic>
 #include <type_traits>
 
+#ifndef ATT_SPLIT_DIAG
+#define ATT_SPLIT_DIAG 0   // diagnostic builds (wrong results): 1 = every slot reads pc row 0 (scalar loads all hit), 2 = no tile DMA,
+#endif                     // 3 = no score loop, 4 = no aggregation
 #ifndef ATT_SPLIT_DB
 #define ATT_SPLIT_DB 0   // 1: row blocks double buffered in registers (64 VGPRs of rows: spills at the 128-register budget)
 #endif
@@ -48,7 +51,8 @@ typedef const f32x4 __attribute__((address_space(4))) * const_f32x4_ptr;
 constexpr int kPartHead = 4;   // floats in front of a partial's O: m, l, (2 unused: O stays 16-byte aligned)
 
 // MODE 0: MLP (relu + w1 dot), 2: cosine (dot of normalised rows), 3: MLP on 2^-64-scaled operands (relu = clamp)
-// NW waves x 4 pairs; FD = Fdim (compile-time: the aggregation's B-operand reads walk the feat image with a stride of Fdim floats —
+// NW = 4 / 8 / 16 waves x 4 pairs (a user's pairs share the staged tile: 64 pairs per workgroup halve the gathered bytes per pair of
+// 32, and a (user, tile) unit of a 64-pairs-per-user batch is ONE workgroup per CU instead of two or three); FD = Fdim (compile-time: the aggregation's B-operand reads walk the feat image with a stride of Fdim floats —
 // with a run-time stride hipcc keeps 16 precomputed addresses per lane, and spills them)
 template <int MODE, int NW, int FD>
 __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitArgs a) {
@@ -100,6 +104,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
         const int64_t b = a.pair_ids[start + j];
         const int blo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffff)), bhi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
         pcrow[k] = a.pc + (((int64_t)bhi << 32) | (unsigned)blo) * a.ldpc;
+#if ATT_SPLIT_DIAG == 1
+        pcrow[k] = a.pc;
+#endif
     }
     if (tid < PP) pid[tid] = tid < cnt ? a.pair_ids[start + tid] : -1;
 
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
                     ci = sub == 2 ? c2 : (sub == 3 ? c3 : ci);
                 }
                 const int jj = xorj ? (j ^ ((e0p + sub) & 15)) : j;
-                dma16(tab + (int64_t)(ci >= 0 ? ci : 0) * ld + 4 * jj, lds_base + (unsigned)piece * 1024u);
+                if (ATT_SPLIT_DIAG != 2) dma16(tab + (int64_t)(ci >= 0 ? ci : 0) * ld + 4 * jj, lds_base + (unsigned)piece * 1024u);
             }
             return;
         }
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
             }
         };
         auto score_dispatch = [&](const f32x4 (&row)[CB], int blk) {
+            if (ATT_SPLIT_DIAG == 3) return;
             if (np > 2) score_block(row, blk, std::integral_constant<int, 4>{});
             else if (np == 2) score_block(row, blk, std::integral_constant<int, 2>{});
             else if (np == 1) score_block(row, blk, std::integral_constant<int, 1>{});
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
             for (int n = 0; n < NJ; ++n) {
                 const int job = wave + NW * n;
                 const int mt = job % MT, nt = job / MT;
-                if (nt >= NTILES) break;                   // wave-uniform
+                if (nt >= NTILES || ATT_SPLIT_DIAG == 4) break;   // wave-uniform
                 const f32x4 s4 = *reinterpret_cast<const f32x4*>(scl + 16 * mt + 4 * g4);   // accumulator register i holds pair row 16*mt + 4*g4 + i
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[n][i] *= s4[i];
@@ -397,8 +405,8 @@ extern "C" size_t ncf_attn_split_workspace_bytes(int64_t B, int Fdim, int nsplit
 extern "C" int ncf_attn_split_supported(int mode, int A, int Fdim, int pairs_per_wg) {
     if (mode != NCF_ATT_MLP && mode != NCF_ATT_COS && mode != NCF_ATT_MLP_SCALED) return 0;
     if (A <= 0 || A % 32 || A > 256 || (Fdim != 64 && Fdim != 128)) return 0;
-    if (pairs_per_wg < 1 || pairs_per_wg > 32) return 0;
-    const int pp = pairs_per_wg <= 16 ? 16 : 32;
+    if (pairs_per_wg < 1 || pairs_per_wg > 64) return 0;
+    const int pp = pairs_per_wg <= 16 ? 16 : (pairs_per_wg <= 32 ? 32 : 64);
     const size_t lds = ((size_t)64 * (A + Fdim) + pp * 66 + pp + 2 * pp) * 4;
     return lds <= 160 * 1024;
 }
@@ -434,7 +442,7 @@ extern "C" int ncf_attn_forward_split(int mode, const float* pc, int64_t ldpc, c
     a.ppw = pairs_per_wg; a.nsplit = nsplit; a.ldpart = Fdim + kPartHead;
     a.b1 = b1;
     const unsigned blocks = (unsigned)((B + pairs_per_wg - 1) / pairs_per_wg + (R < B ? R : B));   // upper bound on sum_r ceil(n_r / ppw)
-    const int pp = pairs_per_wg <= 16 ? 16 : 32;
+    const int pp = pairs_per_wg <= 16 ? 16 : (pairs_per_wg <= 32 ? 32 : 64);   // 4 / 8 / 16 waves of 4 pairs
     const size_t lds = ((size_t)64 * (A + Fdim) + pp * 66 + pp + 2 * pp) * 4;
     auto raise_lds = [&](const void* fn, std::atomic<unsigned long long>& done) -> bool {
         int dev = 0;
@@ -456,7 +464,7 @@ extern "C" int ncf_attn_forward_split(int mode, const float* pc, int64_t ldpc, c
         hipLaunchKernelGGL((attn_split_kernel<M, W, J>), dim3(blocks, (unsigned)nsplit), dim3(64 * W), lds, s, a);        \
     } while (0)
 #define LAUNCH_SP_J(M, W) do { if (Fdim == 64) LAUNCH_SP(M, W, 64); else LAUNCH_SP(M, W, 128); } while (0)
-#define LAUNCH_SP_W(M) do { if (pp == 16) LAUNCH_SP_J(M, 4); else LAUNCH_SP_J(M, 8); } while (0)
+#define LAUNCH_SP_W(M) do { if (pp == 16) LAUNCH_SP_J(M, 4); else if (pp == 32) LAUNCH_SP_J(M, 8); else LAUNCH_SP_J(M, 16); } while (0)
     if (mode == NCF_ATT_COS) LAUNCH_SP_W(2);
     else if (scaled) LAUNCH_SP_W(3);
     else LAUNCH_SP_W(0);

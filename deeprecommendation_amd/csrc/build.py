@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["abi.hip", "gather.hip", "mlp_fused.hip", "linear.hip", "spmm.hip", "attn.hip", "attn_split.hip", "mlp_bf16.hip", "mlp_bf16_ws8.hip", "backward.hip", "exchange.hip"]
+SOURCES = ["abi.hip", "gather.hip", "mlp_fused.hip", "linear.hip", "spmm.hip", "attn.hip", "attn_split.hip", "attn_cand.hip", "mlp_bf16.hip", "mlp_bf16_ws8.hip", "backward.hip", "exchange.hip"]
 LIB = os.path.join(PKG, "libncf_hip.so")
 ARCH = "gfx950"
 # per-file flags.  mlp_bf16.hip: MFMA accumulators in VGPRs instead of AGPRs (the ReLU / bf16 conversion of the hidden
@@ -34,7 +34,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(HERE, "ncf_common.h"), os.path.join(HERE, "mlp_bf16.h"), os.path.join(HERE, "attn_util.h"), os.path.join(PKG, "..", "include", "ncf_abi.h")]
+    deps = sources() + [os.path.join(HERE, "ncf_common.h"), os.path.join(HERE, "mlp_bf16.h"), os.path.join(HERE, "attn_util.h"), os.path.join(HERE, "group_pairs.h"), os.path.join(PKG, "..", "include", "ncf_abi.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

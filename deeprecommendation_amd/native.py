@@ -63,6 +63,10 @@ SIGNATURES = {
     "ncf_group_pairs_workspace_bytes": (_c_size, [_c_i64]),
     "ncf_group_pairs": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
     "ncf_group_pairs_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
+    "ncf_attn_candidates_supported": (_c_int, [_c_int, _c_int, _c_int]),
+    "ncf_attn_candidates_workspace_bytes": (_c_size, [_c_i64]),
+    "ncf_attn_candidates": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_i64, _c_p, _c_i64,
+                                     _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
     "ncf_attn_split_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
     "ncf_attn_split_workspace_bytes": (_c_size, [_c_i64, _c_int, _c_int]),
     "ncf_attn_forward_split": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
@@ -599,6 +603,47 @@ class Grouping(tuple):
         self = super().__new__(cls, (grp_ptr, pair_ids, wg_ptr))
         self.wg_row = wg_row
         return self
+
+
+def attn_candidates_supported(K: int, N1: int, N2: int) -> bool:
+    return bool(load_library().ncf_attn_candidates_supported(int(K), int(N1), int(N2)))
+
+
+def attn_candidates(x: torch.Tensor, Wi: torch.Tensor, bi: Optional[torch.Tensor], Wc: torch.Tensor, b0: Optional[torch.Tensor],
+                    pair_row: Optional[torch.Tensor] = None, n_rows: int = 0, pairs_per_wg: int = 32):
+    """ncf_attn_candidates: (emb (B, N1), pc (B, N2), grouping or None) — the candidates' ItemEmbeddings and their half of
+    AttentionNet.0 in one launch; with ``pair_row`` (B,) int64 the same launch also lists the pairs by rated set (the ``Grouping``
+    group_pairs() returns).  Shapes: attn_candidates_supported(); the fused grouping needs B, n_rows <= 32768."""
+    lib = load_library()
+    _dev(x, "x")
+    if x.dtype != torch.float32 or Wi.dtype != torch.float32 or Wc.dtype != torch.float32:
+        raise TypeError("attn_candidates computes in fp32")
+    B, K, ldx = _rows2d(x, "x")
+    N1, K2, ldw = _rows2d(Wi, "Wi")
+    N2 = int(Wc.shape[0])
+    if K2 != K or Wc.shape[1] != N1 or not Wc.is_contiguous():
+        raise ValueError("attn_candidates: Wi must be (N1, K) and Wc contiguous (N2, N1)")
+    dev = x.device
+    emb = torch.empty((B, N1), dtype=torch.float32, device=dev)
+    pc = torch.empty((B, N2), dtype=torch.float32, device=dev)
+    grp = None
+    grp_ptr = pair_ids = wg_ptr = wg_row = ws = None
+    nbytes = 0
+    R = int(n_rows)
+    if pair_row is not None:
+        if pair_row.dtype != torch.int64 or pair_row.dim() != 1 or not pair_row.is_contiguous() or pair_row.numel() != B:
+            raise ValueError("pair_row must be contiguous 1-D int64 with one entry per row of x")
+        grp_ptr = torch.empty(R + 1, dtype=torch.int64, device=dev)
+        wg_ptr = torch.empty(R + 1, dtype=torch.int64, device=dev)
+        pair_ids = torch.empty(max(B, 1), dtype=torch.int64, device=dev)
+        wg_row = torch.empty((B + int(pairs_per_wg) - 1) // int(pairs_per_wg) + min(R, B) + 1, dtype=torch.int32, device=dev)
+        nbytes = lib.ncf_attn_candidates_workspace_bytes(R)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        grp = Grouping(grp_ptr, pair_ids[:B], wg_ptr, wg_row)
+    _check(lib.ncf_attn_candidates(_ptr(x), B, ldx, K, _ptr(Wi), ldw, _ptr(bi), N1, _ptr(Wc), _ptr(b0), N2, _ptr(emb), emb.stride(0),
+                                   _ptr(pc), pc.stride(0), _ptr(pair_row), R, int(pairs_per_wg), _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr),
+                                   _ptr(wg_row), _ptr(ws), nbytes, _ptr(_oob_flag(dev)) if pair_row is not None else None, _stream(x)))
+    return emb, pc, grp
 
 
 def attn_split_supported(mode: int, A: int, Fdim: int, pairs_per_wg: int) -> bool:

@@ -220,6 +220,14 @@ class AttentionNCF(_ScoringMixin, NCF):
         li, lu = self.ItemEmbeddings[0], self.UserEmbeddings[0]
         rated_emb, pr, proj = self.precompute_catalog(rated_items, cache)
         pc_kept = None
+        ratings = user_matrix if isinstance(user_matrix, SparseRatings) else SparseRatings.from_dense(user_matrix)
+        shared = ratings.pair_row is not None
+        A_att = self.ItemEmbeddings[0].out_features if self.use_cos_sim_instead else (int(self.att_dense) if self.att_dense else 1)
+        mode_att = native.ATT_COS if self.use_cos_sim_instead else (native.ATT_MLP_SCALED if self.att_dense else native.ATT_LINEAR)
+        grouped = (shared and native.attn_grouped_supported(mode_att, A_att, lu.out_features)
+                   and ratings.pairs_per_row >= SparseRatings.GROUPED_MIN_PAIRS_PER_ROW)
+        grouping = None
+        pc = None
         # never inside a HIP-graph capture: a hit would leave the candidate projections out of the captured graph
         keep = not isinstance(candidate_items, RowsOf) and not torch.cuda.is_current_stream_capturing()
         if isinstance(candidate_items, RowsOf):
@@ -236,10 +244,25 @@ class AttentionNCF(_ScoringMixin, NCF):
             kept = cache.get("candidates") if keep else None
             if kept is not None and kept[0] == ckey:
                 cand_emb, pc_kept = kept[1], kept[2]
+            elif (self.att_dense and not self.use_cos_sim_instead
+                  and native.attn_candidates_supported(li.in_features, li.out_features, int(self.att_dense))):
+                # ONE launch: ItemEmbeddings on the candidates, their half of AttentionNet.0, and (in a spare workgroup) the
+                # batch's pairs listed by rated set for the grouped attention kernel
+                wc, _, b0 = self._att_split(cache)
+                B = candidate_items.shape[0]
+                R = ratings.rowptr.numel() - 1
+                fuse_grouping = grouped and not return_attention_weights and B <= 32768 and R <= 32768
+                ppw = native.default_pairs_per_wg(B)
+                cand_emb, pc, grouping = native.attn_candidates(
+                    candidate_items.float().contiguous(), li.weight.detach(), li.bias.detach(), wc, b0,
+                    ratings.pair_row.to(torch.int64).contiguous() if fuse_grouping else None, R, ppw)
+                if grouping is not None:
+                    grouping = (grouping, ppw)
             else:
                 cand_emb = native.linear(candidate_items.float().contiguous(), li.weight.detach(), li.bias.detach())
-        ratings = user_matrix if isinstance(user_matrix, SparseRatings) else SparseRatings.from_dense(user_matrix)
-        if pc_kept is not None:
+        if pc is not None:
+            pass
+        elif pc_kept is not None:
             pc = pc_kept
         elif self.use_cos_sim_instead:
             pc = native.l2_normalize_rows(cand_emb)
@@ -260,13 +283,11 @@ class AttentionNCF(_ScoringMixin, NCF):
                 mode = native.ATT_MLP_SCALED
             else:
                 mode, w1, b1 = native.ATT_LINEAR, None, 0.0
-        shared = ratings.pair_row is not None
-        if (shared and native.attn_grouped_supported(mode, pc.shape[1], proj.shape[1])
-                and ratings.pairs_per_row >= SparseRatings.GROUPED_MIN_PAIRS_PER_ROW):
+        if grouped:
             # several pairs per rated set: stage each set once per workgroup in LDS (K3 grouped form)
             res = native.attn_forward_grouped(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val,
                                               ratings.pair_row, proj, out_bias=lu.bias.detach(),
-                                              return_weights=return_attention_weights)
+                                              return_weights=return_attention_weights, grouping=grouping)
             if return_attention_weights:
                 out = self._score(cand_emb, None, res[0], None, cache=cache)
                 return out, ratings.expanded().to_dense(res[1])

@@ -360,6 +360,23 @@ int ncf_attn_forward_split(int mode,
                            float* dev_out_feat, int64_t ldout,
                            int nsplit, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
 
+/* The candidate side of AttentionNCF.forward in one launch — models/attention_ncf.py:150 (ItemEmbeddings on the candidates) and
+ * the candidate half of AttentionNet's first Linear (:176-179 with AttentionNet.0.weight split at the cat boundary):
+ *     emb = x . Wi^T + bi   (B, N1);     pc = emb . Wc^T + b0   (B, N2)
+ * x (B, K) rows of ldx floats (4-byte aligned rows are fine: K = 2094 in the reference's data), Wi (N1, K) rows of ldw floats,
+ * Wc contiguous (N2, N1).  With dev_pair_row != NULL a spare workgroup of the same launch also runs ncf_group_pairs_rows on the
+ * batch (B, n_rows <= 32768; same outputs, same workspace size: ncf_attn_candidates_workspace_bytes).
+ * Shapes: N1 in {64, 128}, N2 % 16 == 0, N2 <= 256 (ncf_attn_candidates_supported); else NCF_EUNSUPPORTED (use ncf_linear_forward). */
+int ncf_attn_candidates_supported(int K, int N1, int N2);
+size_t ncf_attn_candidates_workspace_bytes(int64_t n_rows);
+int ncf_attn_candidates(const float* dev_x, int64_t B, int64_t ldx, int K,
+                        const float* dev_Wi, int64_t ldw, const float* dev_bi, int N1,
+                        const float* dev_Wc, const float* dev_b0, int N2,
+                        float* dev_emb, int64_t ldemb, float* dev_pc, int64_t ldpc,
+                        const int64_t* dev_pair_row, int64_t n_rows, int pairs_per_wg,
+                        int64_t* dev_grp_ptr, int64_t* dev_pair_ids, int64_t* dev_wg_ptr, int32_t* dev_wg_row,
+                        void* dev_workspace, size_t workspace_bytes, int32_t* dev_oob_flag, ncf_stream_t stream);
+
 /* out[r, :] = x[r, :] / max(||x[r, :]||_2, 1e-12) — torch.nn.functional.normalize(p=2, dim=1) of the cosine
  * variant, models/attention_ncf.py:167-168. */
 int ncf_l2_normalize_rows(const float* dev_x, int64_t ldx, int64_t R, int E, float* dev_out, int64_t ldout,

@@ -200,7 +200,9 @@ def test_attention_grouped_equals_per_pair_kernel(native, gpu, mode, A, Fdim, R,
                                              out_bias=bias, pairs_per_wg=ppw, return_weights=True)
     out_g2 = native.attn_forward_grouped(m, pc, pr, w1 if mode == "mlp" else None, 0.25, rowptr, col, val, pair_row, feat,
                                          out_bias=bias, pairs_per_wg=ppw)
-    assert torch.equal(out_g, out_g2)                       # asking for the weights does not change the scores
+    # asking for the weights does not change the scores: the weights come from round 2's one-workgroup-per-group kernel, the plain
+    # call may take the entry-split kernel (another order of the softmax partial sums): equal to fp32 rounding, not bit for bit
+    assert_close(out_g, out_g2, rtol=2e-6)
     ex = SparseRatings(rowptr, col, val, I, pair_row=pair_row).expanded()
     out_p, w_p = native.attn_forward(m, pc, pr, w1 if mode == "mlp" else None, 0.25, ex.rowptr, ex.col, ex.val, feat, out_bias=bias)
     assert w_g.shape == w_p.shape
@@ -440,7 +442,7 @@ def test_cfg3_bench_workload_full_size_grouped_kernel(gpu):
 
 @pytest.mark.parametrize("mode_name", ["mlp", "mlp_scaled", "cos"])
 @pytest.mark.parametrize("A,Fdim", [(128, 64), (32, 64), (64, 128), (256, 128)])
-@pytest.mark.parametrize("ppw,nsplit", [(32, 1), (32, 4), (16, 2), (32, 3), (5, 8)])
+@pytest.mark.parametrize("ppw,nsplit", [(32, 1), (32, 4), (16, 2), (32, 3), (5, 8), (64, 4), (64, 1), (40, 2)])
 def test_entry_split_kernel_vs_per_pair(gpu, mode_name, A, Fdim, ppw, nsplit):
     """ncf_attn_forward_split (round 3: (group of pairs) x (slice of the rated set) workgroups + merge of the softmax partials)
     against the per-pair kernel on the same batch: rows of 0, 1, 63, 64, 65, 300 entries (empty slices, ragged last tiles, more
