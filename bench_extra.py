@@ -332,6 +332,7 @@ def run_cfg3(args, ctx):
         rx = r.expanded()
         us_pp = bench.back_to_back_us(lambda: native.attn_forward(native.ATT_MLP_SCALED, pc, pr, w1, b1, rx.rowptr, rx.col, rx.val, proj, out_bias=bias_u), reps=50, settle=10)
         ppw = native.default_pairs_per_wg(B)
+        nsplit = 1
         us_g = us_g_b2b = us_group_prep = None
         if not per_pair:
             grouping = (native.group_pairs(rs.pair_row, rs.rowptr.numel() - 1, ppw), ppw)
@@ -340,12 +341,41 @@ def run_cfg3(args, ctx):
                 return native.attn_forward_grouped(native.ATT_MLP_SCALED, pc, pr, w1, b1, rs.rowptr, rs.col, rs.val, rs.pair_row, proj, out_bias=bias_u,
                                                    grouping=grouping)
 
-            kt = bench.kernel_time("ncf::attn_grouped_sc_kernel", "cfg3", grouped, reps=50, settle=20)
+            nsplit = native.default_attn_nsplit(B, rs.rowptr.numel() - 1, rs.col.numel(), ppw)
+            kt = bench.kernel_time("ncf::attn_split_kernel", "cfg3", grouped, reps=50, settle=20)   # + the 3 us merge of the partials
             us_g, us_g_b2b = kt["us"], kt["us_back_to_back"]
             us_group_prep = bench.back_to_back_us(lambda: native.group_pairs(rs.pair_row, rs.rowptr.numel() - 1, ppw), reps=50, settle=5)
         else:
             kt = bench.kernel_time("ncf::attn_kernel", "cfg3", lambda: native.attn_forward(native.ATT_MLP_SCALED, pc, pr, w1, b1, rx.rowptr, rx.col, rx.val, proj, out_bias=bias_u), reps=50, settle=10)
         lin_us = bench.back_to_back_us(lambda: native.linear(cand, li.weight.detach(), li.bias.detach()), reps=50, settle=5)
+        cand_us = None
+        if native.attn_candidates_supported(Fdim, IE, A) and rs is not None:
+            prow = rs.pair_row.to(torch.int64).contiguous()
+            cand_us = bench.back_to_back_us(lambda: native.attn_candidates(cand, li.weight.detach(), li.bias.detach(), wc, b0, prow, rs.rowptr.numel() - 1, ppw),
+                                            reps=50, settle=5)
+        # second workload: every pair its own user (4096 distinct rated sets): nothing to share, the per-pair kernel
+        distinct = None
+        if not per_pair and os.environ.get("NCF_CFG3_NO_DISTINCT") != "1":
+
+            model_d, catalogue_d, batches_d = cfg3_workload(device, users=B, n_batches=2)
+            model_d.precompute_catalog(catalogue_d)
+
+            def step_d(k):
+                c_, r_ = batches_d[k % len(batches_d)]
+                return model_d(c_, catalogue_d, r_)
+
+            wall_d, _ = _time_steps(step_d, args.warmup, args.steps)
+            rxd = batches_d[0][1].expanded()
+            us_d = bench.back_to_back_us(lambda: native.attn_forward(native.ATT_MLP_SCALED, pc, pr, w1, b1, rxd.rowptr, rxd.col, rxd.val, proj, out_bias=bias_u), reps=30, settle=5)
+            bpp_d = nnz * (A * 4 + UE * 4 + 4 + 4 + 3 * 4)
+            distinct = {"workload": f"the same batch shape with {B} DISTINCT users (one rated set per pair: the model dispatches the per-pair kernel)",
+                        "pairs_per_s": B * args.steps / wall_d, "ms_per_step": wall_d / args.steps * 1e3,
+                        "roofline": {"kernel": "attn_kernel<3> (one wave per pair)", "bound": "cache bandwidth (tables of 51 + 26 MB sit in L2 / the Infinity Cache)",
+                                     "us_per_launch": us_d, "algorithmic_bytes_per_pair": bpp_d, "achieved": bpp_d * B / (us_d * 1e-6) / 1e9,
+                                     "unit": "GB/s of gathered rows", "peak": bench.PEAK_HBM_GBS, "frac": bpp_d * B / (us_d * 1e-6) / 1e9 / bench.PEAK_HBM_GBS,
+                                     "valu_TFLOPs": nnz * (4 * A + 2 * UE + 8) * B / (us_d * 1e-6) / 1e12,
+                                     "note": "frac is against the 8 TB/s HBM figure although the rows come from cache: the guide measures 8.6 TB/s chip-wide for random rows out of the Infinity Cache"}}
+            del model_d, catalogue_d, batches_d
     us = kt["us"]
     # What the kernel executes per (pair, rated entry): A x (add, max, fma) for the score (4 flop per a) + UE x fma for the
     # aggregation (2 flop per feature) + the softmax arithmetic — the reformulated attention (AttentionNet.0 split at the cat
@@ -373,19 +403,22 @@ def run_cfg3(args, ctx):
                        "graph_of_resident_batches_ms_per_step": None if wall_graph_nb is None else wall_graph_nb / args.steps * 1e3,
                        "graph_of_resident_batches_error": graph_nb_err,
                        "graph_error": graph_err},
-            "roofline": {"kernel": "attn_kernel<0>" if per_pair else "attn_grouped_sc_kernel<3,32,8>", "bound": "valu", "achieved": tf,
+            "roofline": {"kernel": "attn_kernel<0>" if per_pair else f"attn_split_kernel<3,{ppw // 4},64> x {nsplit} slices + attn_combine_kernel (one call)", "bound": "valu", "achieved": tf,
                          "peak": bench.PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / bench.PEAK_F32_MFMA_TFLOPS,
                          "traffic": kt["traffic"], "us_per_launch": us, "us_per_launch_basis": kt["basis"], "us_back_to_back": kt["us_back_to_back"],
                          "us_isolated_events": kt["us_isolated_events"],
                          "algorithmic_flop_per_pair": flop_per_pair, "algorithmic_bytes_per_pair": bpp,
                          "algorithmic_bytes_per_launch": bpp * B, "hbm_GBps_at_this_rate": bpp * B / (us * 1e-6) / 1e9,
                          "per_pair_kernel_us": us_pp, "grouped_kernel_us": us_g, "grouping_prep_us": us_group_prep,
-                         "pairs_per_workgroup": ppw, "candidate_linear_us": lin_us,
+                         "pairs_per_workgroup": ppw, "slices_per_rated_set": nsplit, "candidate_linear_us": lin_us,
+                         "candidate_kernel_us": cand_us,
                          "rocprof_avg_us": kt["rocprof_avg_us"], "profile": kt["profile"], "profile_check": kt["profile_check"],
                          "note": "bound = fp32 vector (VALU) issue: the contract's hbm/mfma pair does not describe this kernel — its tiles come "
                                  "from L2 / the Infinity Cache once per workgroup (hbm_GBps_at_this_rate is what it NEEDS, a few % of HBM), "
                                  "and relu sits between the add and the dot, so the matrix cores cannot take the (pair, entry, a) loop; "
                                  "peak = 157.3 TFLOP/s fp32 vector = the fp32 MFMA figure"}}
+    if distinct is not None:
+        line["variants"] = {"distinct_users": distinct}
     if not getattr(args, "no_cpu_baseline", False):
         # CPU oracle, reference formulation (materialised candidate x rated pairs, attention_ncf.py:154-213) on a down-scaled
         # sample: 64 pairs of 16 users against those users' own rated items (the full 4096 x 100k pair grid is 2·B·I·IE floats)

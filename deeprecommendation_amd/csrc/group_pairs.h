@@ -64,14 +64,21 @@ __device__ __forceinline__ void group_small_body(const int64_t* __restrict__ pai
     for (int64_t i = threadIdx.x; i < R; i += NT) counts[i] = 0;
     __syncthreads();
     // The rows of U iterations are loaded FIRST, back to back (clamped index, value selected afterwards): one memory round trip per
-    // U x NT pairs instead of one per NT — as a spare workgroup beside a bandwidth-bound kernel a round trip is microseconds.
+    // U x NT pairs instead of one per NT — as a spare workgroup beside a bandwidth-bound kernel a round trip is microseconds.  The
+    // first U x NT pairs (a whole evaluation batch) stay in registers for the scatter pass.
     constexpr int U = 8;
+    int64_t rr0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t b = (int64_t)u * NT + threadIdx.x;
+        rr0[u] = pair_row[b < B ? b : B - 1];
+    }
     for (int64_t base = 0; base < B; base += (int64_t)U * NT) {   // uniform trip counts: the aggregated atomic is a wave-level operation
         int64_t rr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t b = base + (int64_t)u * NT + threadIdx.x;
-            rr[u] = pair_row[b < B ? b : B - 1];
+            rr[u] = base == 0 ? rr0[u] : pair_row[b < B ? b : B - 1];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -136,7 +143,7 @@ __device__ __forceinline__ void group_small_body(const int64_t* __restrict__ pai
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t b = base + (int64_t)u * NT + threadIdx.x;
-            rr[u] = pair_row[b < B ? b : B - 1];
+            rr[u] = base == 0 ? rr0[u] : pair_row[b < B ? b : B - 1];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

@@ -222,8 +222,9 @@ class AttentionNCF(_ScoringMixin, NCF):
         pc_kept = None
         ratings = user_matrix if isinstance(user_matrix, SparseRatings) else SparseRatings.from_dense(user_matrix)
         shared = ratings.pair_row is not None
-        A_att = self.ItemEmbeddings[0].out_features if self.use_cos_sim_instead else (int(self.att_dense) if self.att_dense else 1)
-        mode_att = native.ATT_COS if self.use_cos_sim_instead else (native.ATT_MLP_SCALED if self.att_dense else native.ATT_LINEAR)
+        att_dense = 0 if self.use_cos_sim_instead else int(self.att_dense or 0)
+        A_att = li.out_features if self.use_cos_sim_instead else (att_dense or 1)
+        mode_att = native.ATT_COS if self.use_cos_sim_instead else (native.ATT_MLP_SCALED if att_dense else native.ATT_LINEAR)
         grouped = (shared and native.attn_grouped_supported(mode_att, A_att, lu.out_features)
                    and ratings.pairs_per_row >= SparseRatings.GROUPED_MIN_PAIRS_PER_ROW)
         grouping = None
@@ -244,8 +245,7 @@ class AttentionNCF(_ScoringMixin, NCF):
             kept = cache.get("candidates") if keep else None
             if kept is not None and kept[0] == ckey:
                 cand_emb, pc_kept = kept[1], kept[2]
-            elif (self.att_dense and not self.use_cos_sim_instead
-                  and native.attn_candidates_supported(li.in_features, li.out_features, int(self.att_dense))):
+            elif att_dense and native.attn_candidates_supported(li.in_features, li.out_features, att_dense):
                 # ONE launch: ItemEmbeddings on the candidates, their half of AttentionNet.0, and (in a spare workgroup) the
                 # batch's pairs listed by rated set for the grouped attention kernel
                 wc, _, b0 = self._att_split(cache)
