@@ -34,6 +34,9 @@ SIGNATURES = {
     "ncf_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
     "ncf_get_option": (_c_int, [ctypes.c_char_p, _c_p]),
     "ncf_bucket_ids": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "ncf_bucket_dedup_table_slots": (_c_size, [_c_i64]),
+    "ncf_bucket_ids_dedup": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "ncf_gather_buckets": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_int, _c_i64, _c_int, _c_p, _c_i64, _c_p, _c_p]),
     "ncf_gather_concat": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int,
                                    _c_p, _c_i64, _c_p, _c_p]),
     "ncf_gather_dot": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p]),
@@ -276,6 +279,43 @@ def bucket_ids(idx: torch.Tensor, rows_per_rank: int, total_rows: int, world: in
     _check(lib.ncf_bucket_ids(_ptr(idx), B, int(rows_per_rank), int(total_rows), int(world), int(cap), _ptr(send), _ptr(slot),
                               _ptr(counts), _ptr(_oob_flag(idx.device)), _ptr(overflow), _stream(idx)))
     return send, slot, counts
+
+
+def bucket_dedup_table_slots(B: int) -> int:
+    return int(load_library().ncf_bucket_dedup_table_slots(int(B)))
+
+
+def bucket_ids_dedup(idx: torch.Tensor, rows_per_rank: int, total_rows: int, world: int, cap: int, send: torch.Tensor,
+                     slot: torch.Tensor, counts: torch.Tensor, overflow: torch.Tensor, hkeys: torch.Tensor, hvals: torch.Tensor):
+    """ncf_bucket_ids_dedup: owner bucketing with every DISTINCT id listed once.  ``send`` (world*(cap+1),) int64 = buckets of
+    [count, ids...]; ``slot`` (B,) int64 = each pair's row in the exchanged (world*cap)-row buffer (-1 = dropped); ``counts`` (world,)
+    int32 = distinct ids per owner (may exceed cap); ``hkeys`` / ``hvals``: int64 scratch of bucket_dedup_table_slots(B) slots.
+    Sticky flags on the device, no host sync."""
+    lib = load_library()
+    _dev(idx, "idx")
+    idx = _idx(idx)
+    B = idx.numel()
+    H = min(hkeys.numel(), hvals.numel())
+    if (send.dtype != torch.int64 or send.numel() < world * (cap + 1) or slot.dtype != torch.int64 or slot.numel() < B
+            or counts.dtype != torch.int32 or counts.numel() < world or overflow.dtype != torch.int32
+            or hkeys.dtype != torch.int64 or hvals.dtype != torch.int64):
+        raise ValueError("bucket_ids_dedup: send / slot / hkeys / hvals must be int64 (world*(cap+1) / B / table slots), counts / overflow int32")
+    Hp = 1 << (H.bit_length() - 1)        # the largest power of two the scratch holds
+    _check(lib.ncf_bucket_ids_dedup(_ptr(idx), B, int(rows_per_rank), int(total_rows), int(world), int(cap), _ptr(hkeys), _ptr(hvals), Hp,
+                                    _ptr(send), _ptr(slot), _ptr(counts), _ptr(_oob_flag(idx.device)), _ptr(overflow), _stream(idx)))
+    return send, slot, counts
+
+
+def gather_buckets(table: torch.Tensor, recv: torch.Tensor, world: int, cap: int, out: torch.Tensor) -> torch.Tensor:
+    """ncf_gather_buckets: out[r * cap + k] = table[recv[r][1 + k]] for k < recv[r][0] (buckets of [count, ids...]); padding untouched."""
+    lib = load_library()
+    _dev(table, "table")
+    rows, E, ld = _rows2d(table, "table")
+    if recv.dtype != torch.int64 or recv.numel() < world * (cap + 1) or out.dtype != table.dtype or out.shape[0] < world * cap or out.shape[1] != E:
+        raise ValueError("gather_buckets: recv must be int64 (world*(cap+1),) and out (world*cap, E) of the table's dtype")
+    _check(lib.ncf_gather_buckets(_dt(table), _ptr(table), rows, ld, _ptr(recv), int(world), int(cap), E, _ptr(out), out.stride(0),
+                                  _ptr(_oob_flag(table.device)), _stream(table)))
+    return out
 
 
 # ------------------------------------------------------------------ K2 generic

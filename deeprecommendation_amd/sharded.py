@@ -2,11 +2,15 @@
 
 * ``RowShardedTable`` / ``ShardedBasicNCF`` — BASELINE config 5: embedding tables sharded row-wise over the ranks
   (contiguous row ranges), batch data-parallel.  Two exchange forms:
-    - ``bounded`` (default): owner bucketing on the device (ncf_bucket_ids: one histogram + slot pass, no sort) into a
-      FIXED-capacity buffer, so that the id all-to-all and the row all-to-all use equal splits and no size ever
-      travels to the host: zero host synchronisations per step.  The capacity is agreed once (largest bucket of a
-      sample batch over all ranks x slack); a bucket that outgrows it sets a sticky device flag that ``check()``
-      turns into ``ExchangeOverflow`` (the caller grows the capacity and repeats the pass — like the out-of-range flag).
+    - ``bounded`` (default): owner bucketing on the device into a FIXED-capacity buffer, so that the id all-to-all and the
+      row all-to-all use equal splits and no size ever travels to the host: zero host synchronisations per step.  Round 3:
+      the bucketing DE-DUPLICATES on the device (ncf_bucket_ids_dedup: a hash set in device memory, no sort — every
+      distinct id of the batch travels once, all its pairs share the row that comes back) and every bucket carries its
+      count, so the owner gathers only the rows that were asked for (ncf_gather_buckets) and the statistics know how
+      many of the shipped slots were padding.  The capacity is agreed once (largest bucket of DISTINCT ids of a sample
+      batch over all ranks + a margin of a few standard deviations); a bucket that outgrows it sets a sticky device flag
+      that ``check()`` — a COLLECTIVE: every rank raises the same exception — turns into ``ExchangeOverflow``; every rank
+      then calls ``grow_capacity()`` and repeats the pass.
       ``submit()`` runs the exchange of step t+1 on a second stream under step t's MLP; ``score()`` waits on its event.
     - ``unique``: torch.unique of the ids (sorted -> contiguous owner buckets, duplicates travel once), exact split
       sizes (one host read per lookup).  For traffic with many repeated ids per batch (Zipf), where de-duplication
@@ -34,8 +38,9 @@ from . import native
 
 
 class ExchangeOverflow(RuntimeError):
-    """A rank's bucket for one owner outgrew the agreed capacity: the affected pairs were scored as out-of-range rows.
-    Grow the capacity (``RowShardedTable.set_capacity`` / ``negotiate_capacity``) and repeat the pass."""
+    """Some rank's bucket for one owner outgrew the agreed capacity: the affected pairs were scored as out-of-range rows.
+    Raised by ``check()`` on EVERY rank of the group (the flags are all-reduced), so that every rank takes the same
+    recovery: ``grow_capacity()`` (or ``negotiate_capacity`` / ``set_capacity`` with the same value everywhere) and repeat the pass."""
 
 
 class _HipOps:
@@ -48,6 +53,19 @@ class _HipOps:
     @staticmethod
     def bucket_ids(idx, rows_per_rank, total_rows, world, cap, send, slot, counts, overflow):
         return native.bucket_ids(idx, rows_per_rank, total_rows, world, cap, send, slot, counts, overflow)
+
+    @staticmethod
+    def bucket_ids_dedup(idx, rows_per_rank, total_rows, world, cap, send, slot, counts, overflow, hkeys, hvals):
+        return native.bucket_ids_dedup(idx, rows_per_rank, total_rows, world, cap, send, slot, counts, overflow, hkeys, hvals)
+
+    @staticmethod
+    def gather_buckets(table, recv, world, cap, out):
+        return native.gather_buckets(table, recv, world, cap, out)
+
+    @staticmethod
+    def device_flags(device):
+        """The library's sticky out-of-range flag on this device, as a (1,) int32 tensor (all-reduced by check())."""
+        return native._oob_flag(device)
 
     @staticmethod
     def score(tabA, idxA, tabB, idxB, packed, weights, biases):
@@ -118,24 +136,30 @@ class Comm:
 class _ExchangeBuffers:
     """Device buffers of one in-flight bounded lookup (allocated once, reused every ``depth`` steps)."""
 
-    def __init__(self, world, cap, E, dtype, device, batch):
+    def __init__(self, world, cap, E, dtype, device, batch, dedup=True, table_slots=0):
         n = world * cap
         self.cap = cap
-        self.send = torch.empty(n, dtype=torch.int64, device=device)
-        self.recv_ids = torch.empty(n, dtype=torch.int64, device=device)
+        self.dedup = dedup
+        hdr = 1 if dedup else 0                     # de-duplicating buckets carry their count in front: [count, ids...]
+        self.send = torch.empty(world * (cap + hdr), dtype=torch.int64, device=device)
+        self.recv_ids = torch.empty(world * (cap + hdr), dtype=torch.int64, device=device)
         self.rows_out = torch.empty((n, E), dtype=dtype, device=device)
         self.rows_in = torch.empty((n, E), dtype=dtype, device=device)
         self.slot = torch.empty(max(batch, 1), dtype=torch.int64, device=device)
         self.counts = torch.empty(world, dtype=torch.int32, device=device)
+        if dedup:                                   # hash set of the batch's ids (keys / bucket slots), caller-owned scratch
+            self.hkeys = torch.empty(max(table_slots, 1), dtype=torch.int64, device=device)
+            self.hvals = torch.empty(max(table_slots, 1), dtype=torch.int64, device=device)
 
 
 class RowShardedTable:
     """Rows ``[rank*rpr, min((rank+1)*rpr, total))`` of a (total_rows, E) table live on this rank."""
 
-    CAP_SLACK = 1.25      # capacity = largest bucket seen at negotiation x slack, rounded up to CAP_ROUND ids
-    CAP_ROUND = 256
+    CAP_SIGMAS = 8.0      # capacity = largest bucket seen at negotiation + CAP_SIGMAS * sqrt(that) + CAP_ROUND, rounded up to CAP_ROUND:
+    CAP_ROUND = 64        # a bucket of n ids fluctuates by ~sqrt(n) from batch to batch (8192 ids: +9 % instead of round 2's +25 %)
+    GROW = 1.5            # grow_capacity() factor
 
-    def __init__(self, local_rows: torch.Tensor, total_rows: int, group=None, local_ops=None, comm=None):
+    def __init__(self, local_rows: torch.Tensor, total_rows: int, group=None, local_ops=None, comm=None, dedup=True):
         self.comm = comm if comm is not None else Comm(group)   # `comm`: an object with Comm's interface (tests: a loopback)
         self.group = group
         self.world, self.rank = self.comm.world, self.comm.rank
@@ -150,7 +174,11 @@ class RowShardedTable:
         self.last_stats = {}
         self.last_oob = False
         self.cap = None
+        self.dedup = bool(dedup)
         self.overflow = torch.zeros(1, dtype=torch.int32, device=self.local.device)
+        # statistics of the bounded exchange since the last check(), kept on the device (read by check()): ids asked for,
+        # distinct ids listed (= rows that had to travel or be gathered locally), of which for OTHER ranks, lookups
+        self._stat = torch.zeros(4, dtype=torch.int64, device=self.local.device)
 
     @staticmethod
     def shard_bounds(total_rows: int, world: int, rank: int):
@@ -202,46 +230,120 @@ class RowShardedTable:
 
     def negotiate_capacity(self, idx: torch.Tensor, slack: Optional[float] = None) -> int:
         """Agree ONCE on the per-owner capacity of the exchange buffers: the largest bucket of this sample batch over all
-        ranks (one all-reduce MAX, one host read) x slack.  Every rank must call it with its own batch."""
-        owner = torch.div(idx.clamp(0, max(self.total_rows - 1, 0)), self.rows_per_rank, rounding_mode="floor")
+        ranks (distinct ids when the exchange de-duplicates; one all-reduce MAX, one host read) plus a margin.  Every rank must
+        call it with its own batch.  ``slack``: a factor on the largest bucket instead of the sigma margin."""
+        ids = idx.clamp(0, max(self.total_rows - 1, 0))
+        if self.dedup:
+            ids = torch.unique(ids)
+        owner = torch.div(ids, self.rows_per_rank, rounding_mode="floor")
         mx = torch.bincount(owner, minlength=self.world).max().view(1)
         if self.world > 1:
             self.comm.all_reduce(mx, dist.ReduceOp.MAX)
-        need = int(mx.item() * (self.CAP_SLACK if slack is None else slack)) + 1
+        m = int(mx.item())
+        need = int(m * slack) + 1 if slack is not None else int(m + self.CAP_SIGMAS * m ** 0.5) + self.CAP_ROUND
+        self.cap = (need + self.CAP_ROUND - 1) // self.CAP_ROUND * self.CAP_ROUND
+        return self.cap
+
+    def grow_capacity(self, factor: Optional[float] = None) -> int:
+        """After ExchangeOverflow: every rank calls this (check() raised on all of them) and gets the same larger capacity."""
+        if self.cap is None:
+            raise RuntimeError("capacity not set")
+        need = int(self.cap * (self.GROW if factor is None else factor)) + 1
         self.cap = (need + self.CAP_ROUND - 1) // self.CAP_ROUND * self.CAP_ROUND
         return self.cap
 
     def new_buffers(self, batch: int) -> _ExchangeBuffers:
         if self.cap is None:
             raise RuntimeError("capacity not set: call negotiate_capacity(sample_ids) or set_capacity(cap) first")
-        return _ExchangeBuffers(self.world, self.cap, self.local.shape[1], self.local.dtype, self.local.device, batch)
+        slots = 0
+        if self.dedup:
+            slots = 1024
+            while slots < 2 * max(batch, 1):
+                slots <<= 1
+        return _ExchangeBuffers(self.world, self.cap, self.local.shape[1], self.local.dtype, self.local.device, batch,
+                                dedup=self.dedup, table_slots=slots)
 
     def lookup_bounded(self, idx: torch.Tensor, buf: _ExchangeBuffers):
         """(rows, slot) with rows[slot[p]] == table[idx[p]], through ``buf``; everything is enqueued on the current
         stream and nothing is read back: bucket kernel -> all-to-all of the id buckets (equal splits) -> the owners'
-        K1 gather -> all-to-all of the rows back (equal splits).  Dropped pairs (out of range / over capacity) have
+        gather -> all-to-all of the rows back (equal splits).  Dropped pairs (out of range / over capacity) have
         slot -1 and read as out-of-range rows downstream; see check()."""
         if self.world == 1:
             return self.local, idx.contiguous()
-        if buf.cap != self.cap or idx.numel() > buf.slot.numel():
-            raise ValueError("exchange buffers were built for another capacity / a smaller batch")
-        self.ops.bucket_ids(idx.contiguous(), self.rows_per_rank, self.total_rows, self.world, self.cap, buf.send, buf.slot,
-                            buf.counts, self.overflow)
-        self.comm.all_to_all(buf.recv_ids, buf.send)        # exchange #1: W x cap local row ids, equal splits
-        if self.local.shape[0]:
-            self.ops.gather_rows(self.local, buf.recv_ids, out=buf.rows_out)   # owners gather (HIP K1); padding = row 0
+        if buf.cap != self.cap or idx.numel() > buf.slot.numel() or buf.dedup != self.dedup:
+            raise ValueError("exchange buffers were built for another capacity / a smaller batch / the other bucketing")
+        W, cap = self.world, self.cap
+        if self.dedup:
+            self.ops.bucket_ids_dedup(idx.contiguous(), self.rows_per_rank, self.total_rows, W, cap, buf.send, buf.slot,
+                                      buf.counts, self.overflow, buf.hkeys, buf.hvals)
+            self.comm.all_to_all(buf.recv_ids, buf.send)    # exchange #1: W buckets of [count, ids...], equal splits of cap + 1
+            if self.local.shape[0]:
+                self.ops.gather_buckets(self.local, buf.recv_ids, W, cap, buf.rows_out)   # count rows per bucket; padding untouched
         else:
-            buf.rows_out.zero_()
+            self.ops.bucket_ids(idx.contiguous(), self.rows_per_rank, self.total_rows, W, cap, buf.send, buf.slot,
+                                buf.counts, self.overflow)
+            self.comm.all_to_all(buf.recv_ids, buf.send)    # exchange #1: W x cap local row ids, equal splits
+            if self.local.shape[0]:
+                self.ops.gather_rows(self.local, buf.recv_ids, out=buf.rows_out)   # owners gather (HIP K1); padding = row 0
+            else:
+                buf.rows_out.zero_()
         self.comm.all_to_all(buf.rows_in, buf.rows_out)     # exchange #2: W x cap rows back, equal splits
+        # statistics, on the device (no read): ids asked, ids listed, of which remote, lookups
+        listed = buf.counts[:W].to(torch.int64).clamp(max=cap)
+        self._stat[0] += idx.numel()
+        self._stat[1] += listed.sum()
+        self._stat[2] += listed.sum() - listed[self.rank]
+        self._stat[3] += 1
         return buf.rows_in, buf.slot[:idx.numel()]
 
+    def _flags(self):
+        """(overflow, out-of-range) of this rank as a (2,) int32 tensor on the table's device (no read)."""
+        oob = self.ops.device_flags(self.local.device) if hasattr(self.ops, "device_flags") else None
+        if oob is None:
+            oob = torch.zeros(1, dtype=torch.int32, device=self.local.device)
+        return torch.cat([self.overflow.view(1), oob.view(1).to(self.overflow.dtype)])
+
+    def _clear_flags(self):
+        self.overflow.zero_()
+        oob = self.ops.device_flags(self.local.device) if hasattr(self.ops, "device_flags") else None
+        if oob is not None:
+            oob.zero_()
+
+    def wire_stats(self, reset: bool = True) -> dict:
+        """Traffic of the bounded lookups since the last call (one host read): what travelled and how much of it was padding."""
+        asked, listed, remote, lookups = (int(v) for v in self._stat.tolist())
+        if reset:
+            self._stat.zero_()
+        E, elt = self.local.shape[1], self.local.element_size()
+        cap = self.cap or 0
+        shipped_rows = lookups * (self.world - 1) * cap
+        hdr = 1 if self.dedup else 0
+        return {"lookups": lookups, "ids_asked": asked, "ids_listed": listed, "remote_rows_needed": remote,
+                "rows_shipped_incl_padding": shipped_rows,
+                "row_bytes_on_wire": shipped_rows * E * elt, "row_bytes_needed": remote * E * elt,
+                "id_bytes_on_wire": lookups * (self.world - 1) * (cap + hdr) * 8,
+                "padding_fraction": (1.0 - remote / shipped_rows) if shipped_rows else 0.0,
+                "duplicates_removed_fraction": (1.0 - listed / asked) if asked else 0.0}
+
     def check(self):
-        """Synchronising check of the sticky flags (end of a pass): ExchangeOverflow / IndexError."""
-        if int(self.overflow.item()) != 0:
-            self.overflow.zero_()
-            raise ExchangeOverflow(f"a bucket outgrew the exchange capacity of {self.cap} ids per owner")
-        if self.local.is_cuda and self.ops is _HipOps:
-            native.check_oob(self.local.device)
+        """End of a pass: synchronising, COLLECTIVE check of the sticky flags — every rank of the group must call it and every
+        rank raises the same exception (ExchangeOverflow before IndexError); all flags are cleared first, so a repeated pass
+        starts clean."""
+        _raise_flags(self.comm, [self])
+
+
+def _raise_flags(comm, tables):
+    flags = torch.cat([t._flags() for t in tables])            # per table: overflow, out-of-range (the library's flag is per device)
+    if comm.world > 1:
+        comm.all_reduce(flags, dist.ReduceOp.MAX)
+    vals = flags.tolist()
+    for t in tables:
+        t._clear_flags()
+    if any(vals[0::2]):
+        raise ExchangeOverflow("a bucket outgrew the exchange capacity on some rank (capacities: "
+                               + ", ".join(str(t.cap) for t in tables) + " ids per owner): grow_capacity() on every rank and repeat the pass")
+    if any(vals[1::2]):
+        raise IndexError("index out of range for a sharded embedding table (on some rank)")
 
 
 class _Ticket:
@@ -267,15 +369,15 @@ class ShardedBasicNCF:
 
     def __init__(self, user_table, num_users, item_table, num_items, mlp_weights: Sequence[torch.Tensor],
                  mlp_biases: Sequence[Optional[torch.Tensor]], replicate_items=False, group=None, local_ops=None,
-                 dtype=None, exchange="bounded", depth=2, comm=None):
+                 dtype=None, exchange="bounded", depth=2, comm=None, dedup=True):
         if exchange not in ("bounded", "unique"):
             raise ValueError("exchange must be 'bounded' or 'unique'")
         self.ops = local_ops or _HipOps
         self.exchange = exchange
-        self.users = RowShardedTable(user_table, num_users, group, local_ops, comm)
+        self.users = RowShardedTable(user_table, num_users, group, local_ops, comm, dedup=dedup)
         self.replicate_items = replicate_items
         self.items_full = item_table.contiguous() if replicate_items else None
-        self.items = None if replicate_items else RowShardedTable(item_table, num_items, group, local_ops, comm)
+        self.items = None if replicate_items else RowShardedTable(item_table, num_items, group, local_ops, comm, dedup=dedup)
         self.weights = [w.detach().float().contiguous() for w in mlp_weights]
         self.biases = [None if b is None else b.detach().float().contiguous() for b in mlp_biases]
         self.packed = None
@@ -368,10 +470,23 @@ class ShardedBasicNCF:
     __call__ = forward
 
     def check(self):
-        """End of a pass: raises ExchangeOverflow / IndexError if any step since the last check dropped a pair."""
-        self.users.check()
+        """End of a pass (COLLECTIVE: every rank calls it, every rank raises the same exception): ExchangeOverflow / IndexError if
+        any step on any rank since the last check dropped a pair.  Both tables' flags and the device's out-of-range flag are read
+        in ONE all-reduce and cleared before raising, so the repeated pass starts clean."""
+        _raise_flags(self.users.comm, [self.users] + ([self.items] if self.items is not None else []))
+
+    def grow_capacity(self, factor=None):
+        """After ExchangeOverflow, on every rank: larger buffers for both tables (the same value everywhere)."""
+        caps = {"users": self.users.grow_capacity(factor)}
         if self.items is not None:
-            self.items.check()
+            caps["items"] = self.items.grow_capacity(factor)
+        return caps
+
+    def wire_stats(self, reset=True):
+        out = {"users": self.users.wire_stats(reset)}
+        if self.items is not None:
+            out["items"] = self.items.wire_stats(reset)
+        return out
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -107,6 +107,25 @@ int ncf_bucket_ids(const int64_t* dev_idx, int64_t B, int64_t rows_per_rank, int
                    int64_t* dev_send, int64_t* dev_slot, int32_t* dev_counts,
                    int32_t* dev_oob_flag, int32_t* dev_overflow_flag, ncf_stream_t stream);
 
+/* De-duplicating form of ncf_bucket_ids ("dedup duplicate ids per destination before sending"): every DISTINCT id
+ * of the batch takes one slot of its owner's bucket and all of its pairs share it (dev_slot), through a hash set in device memory
+ * — no sort, no size on the host.  Buckets carry their count: dev_send holds world buckets of (cap + 1) int64,
+ * [count, id_0 .. id_{cap-1}], so the counts travel with the id all-to-all and the owner gathers count rows per bucket
+ * (ncf_gather_buckets); padding is never initialised.  dev_slot[p] indexes the (world * cap) rows that come back.
+ * dev_hkeys / dev_hvals: table_slots >= ncf_bucket_dedup_table_slots(B) int64 each (a power of two >= 2 B), caller-owned scratch.
+ * Flags as ncf_bucket_ids.  The reference has no counterpart (single device). */
+size_t ncf_bucket_dedup_table_slots(int64_t B);
+int ncf_bucket_ids_dedup(const int64_t* dev_idx, int64_t B, int64_t rows_per_rank, int64_t total_rows, int world, int64_t cap,
+                         int64_t* dev_hkeys, int64_t* dev_hvals, int64_t table_slots,
+                         int64_t* dev_send, int64_t* dev_slot, int32_t* dev_counts,
+                         int32_t* dev_oob_flag, int32_t* dev_overflow_flag, ncf_stream_t stream);
+
+/* The owner's gather for the buckets of ncf_bucket_ids_dedup: dev_recv = world buckets of [count, ids ...] as received;
+ * out row (r * cap + k) = table[recv[r][1 + k]] for k < count_r; rows beyond a bucket's count are neither read nor written.
+ * Rows must be multiples of 16 bytes.  An id outside [0, rows) gives a zero row and sets *dev_oob_flag. */
+int ncf_gather_buckets(int dtype, const void* dev_table, int64_t rows, int64_t ld, const int64_t* dev_recv, int world, int64_t cap, int E,
+                       void* dev_out, int64_t ldout, int32_t* dev_oob_flag, ncf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K2  MLP forward, generic layer-by-layer path (any dims)
  * Replaces: nn.Sequential(Linear, [ReLU, Dropout(eval = identity), Linear]*) — util.py:5-18, called at

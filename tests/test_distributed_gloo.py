@@ -48,6 +48,36 @@ class TorchOps:
         return send, slot, counts
 
     @staticmethod
+    def bucket_ids_dedup(idx, rows_per_rank, total_rows, world, cap, send, slot, counts, overflow, hkeys, hvals):
+        """ncf_bucket_ids_dedup restated with torch ops (include/ncf_abi.h): every DISTINCT id once, buckets of [count, ids...]."""
+        ok = (idx >= 0) & (idx < total_rows)
+        uniq, inv = torch.unique(idx[ok], return_inverse=True)           # sorted: contiguous owner ranges
+        owner = uniq // rows_per_rank
+        cnt = torch.bincount(owner, minlength=world)
+        counts.copy_(cnt.to(torch.int32))
+        start = torch.cumsum(cnt, 0) - cnt
+        k = torch.arange(uniq.numel()) - start[owner]
+        keep = k < cap
+        if bool((~keep).any()):
+            overflow[0] = 1
+        s_u = torch.where(keep, owner * cap + k, torch.full_like(uniq, -1))
+        b = send.view(world, cap + 1)
+        b[:, 0] = cnt.clamp(max=cap)
+        b[owner[keep], 1 + k[keep]] = (uniq - owner * rows_per_rank)[keep]
+        out = torch.full_like(idx, -1)
+        out[ok] = s_u[inv]
+        slot[:idx.numel()] = out
+        return send, slot, counts
+
+    @staticmethod
+    def gather_buckets(table, recv, world, cap, out):
+        b = recv.view(world, cap + 1)
+        for r in range(world):
+            n = int(b[r, 0])
+            out[r * cap:r * cap + n] = table[b[r, 1:1 + n]]
+        return out
+
+    @staticmethod
     def score(tabA, idxA, tabB, idxB, packed, weights, biases):
         def rows(tab, idx):  # an index outside the table reads as a zero row (the kernels' out-of-range contract)
             ok = (idx >= 0) & (idx < tab.shape[0])
@@ -136,19 +166,48 @@ def _sharded_worker(rank, world, store_path, replicate_items, exchange="unique")
             model.check()
             # capacity agreed from a sample batch: max bucket over both ranks x 1.25, a multiple of 256
             caps = model.negotiate_capacity(ups[0], ips[0])
-            assert caps["users"] % 256 == 0 and caps["users"] >= 256
             # a bucket beyond the capacity: the flag is raised at check(), on the rank whose bucket overflowed
+            assert caps["users"] % 64 == 0 and caps["users"] >= 64
+            st = model.wire_stats()["users"]
+            assert st["lookups"] > 0 and st["ids_listed"] <= st["ids_asked"] and 0.0 <= st["padding_fraction"] <= 1.0
+            assert st["duplicates_removed_fraction"] > 0.0          # case 2 above repeats one id 50 times
+            # a bucket beyond the capacity on ONE rank: check() is collective — EVERY rank raises ExchangeOverflow, every rank grows
+            # the capacity (the same value everywhere) and the repeated pass is clean on all of them
             model.users.set_capacity(8)
             if model.items is not None:
                 model.items.set_capacity(300)
-            up = torch.full((40,), U - 1, dtype=torch.int64) if rank == 0 else torch.randint(ulo, uhi, (5,), generator=gb)
+            if rank == 0:
+                up = torch.arange(U - 40, U, dtype=torch.int64)       # 40 DISTINCT ids of the last rank: bucket of 8 overflows
+            else:
+                up = torch.randint(ulo, uhi, (5,), generator=gb)      # all local: nothing to overflow here
             ip = torch.randint(0, I, (up.numel(),), generator=gb)
             model(up, ip)
-            if rank == 0:
-                with pytest.raises(ExchangeOverflow):
-                    model.check()
-            else:
+            with pytest.raises(ExchangeOverflow):
                 model.check()
+            model.check()                        # every flag was cleared before raising: no stale overflow / out-of-range left
+            grown = model.grow_capacity(8.0)
+            assert grown["users"] >= 64
+            out = model(up, ip)
+            assert torch.equal(out, O.mlp_forward(torch.cat((tu[up], ti[ip]), 1), list(zip(ws, bs))))
+            model.check()
+            # 40 REPEATS of one id fit a bucket of 8 now: the exchange de-duplicates
+            model.users.set_capacity(8)
+            model._ring = [None] * model.depth
+            up = torch.full((40,), U - 1, dtype=torch.int64) if rank == 0 else torch.randint(ulo, uhi, (5,), generator=gb)
+            ip = torch.randint(0, I, (up.numel(),), generator=gb)
+            out = model(up, ip)
+            assert torch.equal(out, O.mlp_forward(torch.cat((tu[up], ti[ip]), 1), list(zip(ws, bs))))
+            model.check()
+            # an id outside the table on one rank: IndexError on EVERY rank, flags cleared
+            model.users.set_capacity(300)
+            model._ring = [None] * model.depth
+            up = torch.tensor([0, U + 5 if rank == 1 else 1])
+            ip = torch.tensor([0, 1])
+            model(up, ip)
+            if getattr(model.ops, "device_flags", None) is not None:
+                with pytest.raises(IndexError):
+                    model.check()
+            model.check()
         else:
             # an id outside the table: IndexError on the rank that asked for it, collectives stay matched
             up = torch.tensor([0, U if rank == 0 else 1])

@@ -90,6 +90,70 @@ def test_bucket_ids_kernel(gpu, world, cap, B):
         assert bool(used[o * cap:o * cap + n].all()) and not bool(used[o * cap + n:(o + 1) * cap].any())
 
 
+@pytest.mark.parametrize("world,cap,B,zipf", [(8, 1200, 8192, False), (8, 700, 8192, True), (2, 4096, 4097, False), (3, 40, 1000, True),
+                                              (1, 16, 100, False), (64, 3, 5000, False), (8, 16, 0, False)])
+def test_bucket_ids_dedup_kernel_and_bucket_gather(gpu, world, cap, B, zipf):
+    """ncf_bucket_ids_dedup against its definition (include/ncf_abi.h): every DISTINCT valid id is listed once in its owner's bucket
+    (as a local row, buckets filled from their start, header = count), every pair of that id points at that slot, counts are the
+    distinct counts, ids over capacity / out of range are dropped and flagged; and ncf_gather_buckets returns exactly the rows the
+    slots name (padding untouched)."""
+    from deeprecommendation_amd import native
+    total = 100_003
+    rpr = (total + world - 1) // world
+    g = torch.Generator().manual_seed(world * 1000 + B + 7)
+    if zipf:       # heavy repeats
+        idx = (torch.rand(B, generator=g) ** 6 * total).long().clamp(0, total - 1)
+    else:
+        idx = torch.randint(0, total, (B,), generator=g)
+    if B > 100:
+        idx[5], idx[77] = -3, total + 9          # two ids outside the table
+        idx[10:20] = idx[9]                      # a run of repeats
+    d = idx.to(gpu)
+    H = native.bucket_dedup_table_slots(B)
+    send = torch.full((world * (cap + 1),), -7, dtype=torch.int64, device=gpu)
+    slot = torch.full((max(B, 1),), -7, dtype=torch.int64, device=gpu)
+    counts = torch.full((world,), -7, dtype=torch.int32, device=gpu)
+    overflow = torch.zeros(1, dtype=torch.int32, device=gpu)
+    hk, hv = torch.empty(H, dtype=torch.int64, device=gpu), torch.empty(H, dtype=torch.int64, device=gpu)
+    native.bucket_ids_dedup(d, rpr, total, world, cap, send, slot, counts, overflow, hk, hv)
+    if B > 100:
+        with pytest.raises(IndexError):
+            native.check_oob(gpu)
+    else:
+        native.check_oob(gpu)
+    send_c, slot_c, counts_c = send.cpu().view(world, cap + 1), slot.cpu()[:B], counts.cpu()
+    ok = (idx >= 0) & (idx < total)
+    uniq = torch.unique(idx[ok])
+    expect = torch.bincount(uniq // rpr, minlength=world)
+    assert torch.equal(counts_c.long(), expect)
+    assert int(overflow.item()) == int(bool((expect > cap).any()))
+    assert torch.equal(send_c[:, 0], torch.minimum(expect, torch.tensor(cap)))          # bucket headers
+    kept = slot_c >= 0
+    assert not bool(kept[~ok].any())
+    owner = torch.where(ok, idx // rpr, torch.zeros_like(idx))
+    assert torch.equal(slot_c[kept] // cap, owner[kept])                                   # the right bucket
+    k = slot_c[kept] % cap
+    assert bool((k < send_c[owner[kept], 0]).all())                                        # inside the bucket's filled prefix
+    assert torch.equal(send_c[owner[kept], 1 + k], (idx - owner * rpr)[kept])              # holding the right local row
+    # one slot per distinct id: pairs with equal ids share it, distinct ids never do
+    assert torch.unique(slot_c[kept]).numel() == torch.unique(idx[kept]).numel()
+    assert torch.unique(torch.stack([slot_c[kept], idx[kept]]), dim=1).shape[1] == torch.unique(slot_c[kept]).numel()
+    if not bool((expect > cap).any()):
+        assert bool(kept[ok].all())
+    # the owner's side (all buckets "received" by one table here): rows of exactly the listed ids
+    tab = torch.randn(rpr, 128, generator=g).to(torch.bfloat16).to(gpu)
+    out = torch.full((world * cap, 128), 7.0, dtype=torch.bfloat16, device=gpu)
+    native.gather_buckets(tab, send, world, cap, out)
+    native.check_oob(gpu)
+    out_c, tab_c = out.cpu(), tab.cpu()
+    for o in range(world):
+        n = int(send_c[o, 0])
+        assert torch.equal(out_c[o * cap:o * cap + n], tab_c[send_c[o, 1:1 + n]])
+        assert bool((out_c[o * cap + n:(o + 1) * cap] == 7.0).all())                       # padding: neither gathered nor written
+    if B:
+        assert torch.equal(out_c[slot_c[kept]], tab_c[(idx - owner * rpr)[kept]])           # what a pair reads back is its row
+
+
 def _two_rank_worker(rank, world, store, exchange, replicate):
     """Both ranks on cuda:0, gloo transport (device tensors staged through the host): the HIP local compute, the device
     bucketing and the two-stream pipeline of ShardedBasicNCF, checked bit for bit against the unsharded fused kernel."""
@@ -127,7 +191,21 @@ def _two_rank_worker(rank, world, store, exchange, replicate):
             ref = native.score_fused(tu, ups[k], ti, ips[k], packed)
             assert torch.equal(outs[k], ref), f"rank {rank} batch {k} ({exchange})"
         if exchange == "bounded":
-            assert model._xstream is not None and model.users.cap % 256 == 0
+            assert model._xstream is not None and model.users.cap % 64 == 0
+            st = model.wire_stats()["users"]
+            assert st["lookups"] == n and st["ids_asked"] == n * B and 0 < st["ids_listed"] <= st["ids_asked"]
+            assert 0.0 < st["padding_fraction"] < 0.5 and st["remote_rows_needed"] < st["ids_listed"]
+            # overflow -> every rank raises -> grow on every rank -> repeat -> clean check (no stale flags left behind)
+            from deeprecommendation_amd.sharded import ExchangeOverflow
+            model.users.set_capacity(64)
+            model(ups[0], ips[0])
+            with pytest.raises(ExchangeOverflow):
+                model.check()
+            model.check()
+            model.grow_capacity(80.0)
+            out = model(ups[0], ips[0])
+            model.check()
+            assert torch.equal(out, native.score_fused(tu, ups[0], ti, ips[0], packed))
     finally:
         dist.destroy_process_group()
 
