@@ -66,6 +66,9 @@ SIGNATURES = {
     "ncf_group_pairs_workspace_bytes": (_c_size, [_c_i64]),
     "ncf_group_pairs": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
     "ncf_group_pairs_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
+    "ncf_dense_csr_workspace_bytes": (_c_size, [_c_i64]),
+    "ncf_dense_csr_rows": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_size, _c_p]),
+    "ncf_dense_csr_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "ncf_attn_candidates_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "ncf_attn_candidates_workspace_bytes": (_c_size, [_c_i64]),
     "ncf_attn_candidates": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_i64, _c_p, _c_i64,
@@ -645,6 +648,34 @@ class Grouping(tuple):
         return self
 
 
+DENSE_CSR_MAX_ENTRIES = 1 << 26     # col / val are sized for the worst case B * I: beyond 64 M entries the host-sized path is used
+
+
+def dense_to_csr(user_matrix: torch.Tensor, share_rows: bool = True):
+    """(rowptr (B+1) int64, col int32, val fp32, pair_row (B) int64) of a dense (B, I) user_matrix, entirely on the stream
+    (ncf_dense_csr_rows + cumsum + ncf_dense_csr_fill; no host read).  The CSR has B rows; with ``share_rows`` a row that equals an
+    earlier one is empty and pair_row points at the earlier one.  col / val are sized B * I (only rowptr[B] entries are written)."""
+    lib = load_library()
+    _dev(user_matrix, "user_matrix")
+    if user_matrix.dtype != torch.float32:
+        raise TypeError("dense_to_csr takes an fp32 matrix")
+    B, I, ld = _rows2d(user_matrix, "user_matrix")
+    dev = user_matrix.device
+    pair_row = torch.empty(B, dtype=torch.int64, device=dev)
+    rowptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    col = torch.empty(max(B * I, 1), dtype=torch.int32, device=dev)
+    val = torch.empty(max(B * I, 1), dtype=torch.float32, device=dev)
+    if B == 0:
+        return rowptr, col, val, pair_row
+    keep = torch.empty(B, dtype=torch.int64, device=dev)
+    nbytes = lib.ncf_dense_csr_workspace_bytes(B)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _check(lib.ncf_dense_csr_rows(_ptr(user_matrix), ld, B, I, 1 if share_rows else 0, _ptr(pair_row), _ptr(keep), _ptr(ws), nbytes, _stream(user_matrix)))
+    torch.cumsum(keep, 0, out=rowptr[1:])
+    _check(lib.ncf_dense_csr_fill(_ptr(user_matrix), ld, B, I, _ptr(rowptr), _ptr(pair_row), _ptr(col), _ptr(val), _stream(user_matrix)))
+    return rowptr, col, val, pair_row
+
+
 def attn_candidates_supported(K: int, N1: int, N2: int) -> bool:
     return bool(load_library().ncf_attn_candidates_supported(int(K), int(N1), int(N2)))
 
@@ -708,7 +739,7 @@ def num_cus() -> int:
 def attn_forward_grouped(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[torch.Tensor], b1: float,
                          rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, pair_row: torch.Tensor,
                          feat: torch.Tensor, out_bias: Optional[torch.Tensor] = None, pairs_per_wg: Optional[int] = None,
-                         grouping=None, return_weights: bool = False, nsplit: Optional[int] = None):
+                         grouping=None, return_weights: bool = False, nsplit: Optional[int] = None, nnz_hint: Optional[int] = None):
     """LDS-tiled attention for pairs that share rated sets: CSR row ``pair_row[b]`` is pair b's set.  Returns out_feat
     (B, Fdim), or (out_feat, weights) with ``return_weights``: the attention weights in the layout of the expanded
     per-pair CSR (``SparseRatings.expanded()``).  ``grouping`` = (group_pairs(pair_row, R, ppw), ppw) computed earlier
@@ -738,7 +769,7 @@ def attn_forward_grouped(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Opti
     if (not return_weights and get_option("attn_grouped_kernel") == 0
             and lib.ncf_attn_split_supported(mode, A, Fdim, int(pairs_per_wg)) and I > 0):
         # entry-split form (round 3): (group of pairs) x (slice of the rated set) workgroups + a merge of the softmax partials
-        ns = int(nsplit) if nsplit is not None else default_attn_nsplit(B, R, col.numel(), int(pairs_per_wg))
+        ns = int(nsplit) if nsplit is not None else default_attn_nsplit(B, R, col.numel() if nnz_hint is None else int(nnz_hint), int(pairs_per_wg))
         nbytes = lib.ncf_attn_split_workspace_bytes(B, Fdim, ns)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=pc.device) if ns > 1 else None
         _check(lib.ncf_attn_forward_split(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), float(b1), _ptr(rowptr), _ptr(col),

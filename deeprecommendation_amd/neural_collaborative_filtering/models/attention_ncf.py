@@ -131,6 +131,20 @@ class SparseRatings:
         return SparseRatings(rowptr, nz[:, 1].to(torch.int32).contiguous(), user_matrix[mask].float().contiguous(),
                              user_matrix.shape[1])
 
+    @staticmethod
+    def from_dense_on_stream(user_matrix: torch.Tensor) -> "SparseRatings":
+        """``from_dense`` without a single host read (libncf_hip.so: ncf_dense_csr_rows + a cumulative sum + ncf_dense_csr_fill, all
+        on the current stream): rows that are exactly equal share one CSR row — found by a row hash, VERIFIED element by element on
+        the device.  The CSR keeps B rows (a row that shares another's is empty) and ``col`` / ``val`` are sized for the worst case
+        B * I, of which rowptr[B] entries are valid: sizes the host never learns.  What the host cannot know either is how much
+        sharing there is; the reference's callers repeat rows (datasets/dynamic_datasets.py:24-40, webapp/backend.py:78-121), so the
+        result carries ``pairs_per_row_hint`` = the grouped kernels' threshold: they are correct for any amount of sharing."""
+        rowptr, col, val, pair_row = native.dense_to_csr(user_matrix.contiguous())
+        r = SparseRatings(rowptr, col, val, user_matrix.shape[1], pair_row=pair_row,
+                          pairs_per_row_hint=SparseRatings.GROUPED_MIN_PAIRS_PER_ROW)
+        r.nnz_hint = max(1, user_matrix.shape[1] // 4) * user_matrix.shape[0]     # for launch geometry only (slices per rated set)
+        return r
+
     def to_dense(self, values: torch.Tensor) -> torch.Tensor:
         if self.pair_row is not None:
             ex = self.expanded()   # `values` may be aligned with the shared entries (e.g. self.val) or the expanded ones
@@ -144,6 +158,9 @@ class SparseRatings:
 
 class AttentionNCF(_ScoringMixin, NCF):
     compatible_datasets = ("DynamicPointwiseDataset", "DynamicRankingDataset")
+    # a dense (B, I) user_matrix is converted to shared-row CSR on the stream (no host read; the grouped kernels are used whatever the
+    # sharing turns out to be).  False: round 2's conversion — two host reads, exact choice between the grouped and the per-pair kernel.
+    dense_user_matrix_on_stream = True
 
     def __init__(self, item_dim, item_emb=128, user_emb=128, att_dense=None, mlp_dense_layers=None,
                  use_cos_sim_instead=False, dropout_rate=0.2, message_dropout=None):
@@ -220,7 +237,13 @@ class AttentionNCF(_ScoringMixin, NCF):
         li, lu = self.ItemEmbeddings[0], self.UserEmbeddings[0]
         rated_emb, pr, proj = self.precompute_catalog(rated_items, cache)
         pc_kept = None
-        ratings = user_matrix if isinstance(user_matrix, SparseRatings) else SparseRatings.from_dense(user_matrix)
+        if isinstance(user_matrix, SparseRatings):
+            ratings = user_matrix
+        elif (user_matrix.is_cuda and user_matrix.dtype == torch.float32 and not return_attention_weights
+              and 0 < user_matrix.numel() <= native.DENSE_CSR_MAX_ENTRIES and self.dense_user_matrix_on_stream):
+            ratings = SparseRatings.from_dense_on_stream(user_matrix)      # the reference's call shape, no host round trip
+        else:
+            ratings = SparseRatings.from_dense(user_matrix)
         shared = ratings.pair_row is not None
         att_dense = 0 if self.use_cos_sim_instead else int(self.att_dense or 0)
         A_att = li.out_features if self.use_cos_sim_instead else (att_dense or 1)
@@ -287,7 +310,8 @@ class AttentionNCF(_ScoringMixin, NCF):
             # several pairs per rated set: stage each set once per workgroup in LDS (K3 grouped form)
             res = native.attn_forward_grouped(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val,
                                               ratings.pair_row, proj, out_bias=lu.bias.detach(),
-                                              return_weights=return_attention_weights, grouping=grouping)
+                                              return_weights=return_attention_weights, grouping=grouping,
+                                              nnz_hint=getattr(ratings, "nnz_hint", None))
             if return_attention_weights:
                 out = self._score(cand_emb, None, res[0], None, cache=cache)
                 return out, ratings.expanded().to_dense(res[1])

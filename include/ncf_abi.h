@@ -379,6 +379,23 @@ int ncf_attn_forward_split(int mode,
                            float* dev_out_feat, int64_t ldout,
                            int nsplit, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
 
+/* Dense user_matrix -> CSR with shared rows, on the stream (no size is read by the host).  The reference passes AttentionNCF.forward a
+ * dense (B, I) user_matrix in which a user's row is repeated for each of their samples (datasets/dynamic_datasets.py:24-40,
+ * content_providers/dynamic_profiles_provider.py:55-71; one row for every candidate in webapp/backend.py:78-121) and keeps the
+ * entries != 0 (models/attention_ncf.py:158).  Two calls around one cumulative sum the caller runs on the stream:
+ *   ncf_dense_csr_rows  -> dev_pair_row[b] = the row pair b uses (the smallest pair index with an IDENTICAL row when share_rows != 0
+ *                          — found by a row hash and verified element by element —, b itself otherwise) and dev_keep_cnt[b] = the
+ *                          entries row b will list (0 for a row that shares another's)
+ *   rowptr = [0, cumsum(dev_keep_cnt)]
+ *   ncf_dense_csr_fill  -> the representatives' (col, val) in column order at rowptr[b]; dev_col / dev_val must hold rowptr[B]
+ *                          entries (B * I is always enough).
+ * -0.0 counts as 0 (unrated); a row containing NaN never shares.  workspace: ncf_dense_csr_workspace_bytes(B), 16-byte aligned. */
+size_t ncf_dense_csr_workspace_bytes(int64_t B);
+int ncf_dense_csr_rows(const float* dev_user_matrix, int64_t ld, int64_t B, int64_t I, int share_rows,
+                       int64_t* dev_pair_row, int64_t* dev_keep_cnt, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
+int ncf_dense_csr_fill(const float* dev_user_matrix, int64_t ld, int64_t B, int64_t I, const int64_t* dev_rowptr,
+                       const int64_t* dev_pair_row, int32_t* dev_col, float* dev_val, ncf_stream_t stream);
+
 /* The candidate side of AttentionNCF.forward in one launch — models/attention_ncf.py:150 (ItemEmbeddings on the candidates) and
  * the candidate half of AttentionNet's first Linear (:176-179 with AttentionNet.0.weight split at the cat boundary):
  *     emb = x . Wi^T + bi   (B, N1);     pc = emb . Wc^T + b0   (B, N2)

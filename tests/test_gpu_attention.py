@@ -495,3 +495,102 @@ def test_entry_split_kernel_out_of_catalogue_columns_and_default_nsplit(gpu):
     assert native.default_attn_nsplit(B, R, col.numel(), native.default_pairs_per_wg(B)) > 1
     out = native.attn_forward_grouped(native.ATT_MLP, pc, pr, w1, -0.2, rowptr, col, val, who, feat)       # default ppw / nsplit
     assert_close(out, ref)
+
+
+def _dense_batch(gpu, B, I, users, density, seed, with_edge_cases=True):
+    g = torch.Generator().manual_seed(seed)
+    rows = torch.zeros(users, I)
+    mask = torch.rand(users, I, generator=g) < density
+    rows[mask] = (torch.randint(1, 11, (users, I), generator=g).float() * 0.5 - 2.9)[mask]
+    who = torch.randint(0, users, (B,), generator=g)
+    um = rows[who].clone()
+    if with_edge_cases and B >= 8:
+        um[3] = 0.0                                   # a user with no ratings
+        um[5] = um[4]                                 # two pairs with the very same row
+        um[6] = um[4]; um[6, 0] = -0.0 if float(um[4, 0]) == 0.0 else um[4, 0]
+        um[7] = um[4]; um[7, I - 1] += 0.5            # differs from row 4 in the LAST column only
+    return um.to(gpu), who
+
+
+@pytest.mark.parametrize("B,I,users,share", [(64, 50, 7, True), (512, 1174, 64, True), (512, 1174, 64, False), (300, 3000, 300, True), (1, 9, 1, True)])
+def test_dense_to_csr_on_stream(gpu, B, I, users, share):
+    """ncf_dense_csr_rows / _fill against the definition: pair b's CSR row lists exactly the non-zero entries of user_matrix[b]
+    (attention_ncf.py:158) in column order; with sharing, identical rows use ONE row — that of the smallest pair index — and
+    nothing else shares; -0.0 counts as unrated; sizes never touch the host (sync debug mode = error)."""
+    from deeprecommendation_amd import native
+    um, _ = _dense_batch(gpu, B, I, users, 0.15, seed=B + I)
+    if B >= 8:
+        um[2, 1] = -0.0
+    native.dense_to_csr(um, share)                    # warm-up (allocator, library load)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        rowptr, col, val, pair_row = native.dense_to_csr(um, share)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    rowptr, col, val, pair_row, umc = rowptr.cpu(), col.cpu(), val.cpu(), pair_row.cpu(), um.cpu()
+    assert int(rowptr[0]) == 0 and bool((rowptr[1:] >= rowptr[:-1]).all())
+    first = {}
+    for b in range(B):
+        key = tuple(umc[b].tolist())                  # -0.0 == 0.0 as tuple elements? no: compare via the != 0 pattern below
+        nz = (umc[b] != 0).nonzero().view(-1)
+        r = int(pair_row[b])
+        lo, hi = int(rowptr[r]), int(rowptr[r + 1])
+        assert torch.equal(col[lo:hi].long(), nz), f"pair {b}"
+        assert torch.equal(val[lo:hi], umc[b][nz]), f"pair {b}"
+        if share:
+            k = (tuple(nz.tolist()), tuple(umc[b][nz].tolist()))
+            first.setdefault(k, b)
+            assert r == first[k], f"pair {b} must use the row of the first identical pair"
+        else:
+            assert r == b
+    reps = torch.unique(pair_row)
+    assert int(rowptr[-1]) == sum(int((umc[int(r)] != 0).sum()) for r in reps)
+
+
+@pytest.mark.parametrize("name", ["g3_att_dense8", "g3_att_vec64", "g3_att_vec128", "g3_att_cos", "g3_att_none"])
+def test_attention_forward_dense_matrix_without_host_synchronisation(gpu, name):
+    """The reference's own call shape — model(candidates, rated_items, DENSE user_matrix) — through the on-stream conversion:
+    equal to the reference's golden output, and the whole forward enqueues without a single host read
+    (torch.cuda.set_sync_debug_mode("error")) once the weight-derived caches exist."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
+    state, a, kw = load_golden(name)
+    m = AttentionNCF(**kw)
+    m.load_state_dict(state)
+    m = m.eval().to(gpu)
+    cand, rated, um = (torch.from_numpy(a[k]).to(gpu) for k in ("candidate_items", "rated_items", "user_matrix"))
+    ref = torch.from_numpy(a["out"])
+    with torch.no_grad():
+        out = m(cand, rated, um)                      # first call: packs weights, projects the catalogue (may read the host)
+        assert_close(out, ref)
+        cand2, um2 = cand.clone(), um.clone()         # new tensors: no cache of candidate projections applies
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            out2 = m(cand2, rated, um2)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert_close(out2, ref)
+        m.dense_user_matrix_on_stream = False         # round 2's conversion (host reads, exact kernel dispatch): same scores
+        out3 = m(cand.clone(), rated, um.clone())
+        assert_close(out3, out2, rtol=2e-6)
+
+
+def test_attention_forward_dense_matrix_reference_eval_shape(gpu):
+    """B = 512 samples of 64 users (rows repeated as dynamic_datasets.py:24-40 builds them), I = 1174 rated items, F = 2094: the
+    reference's evaluation batch.  On-stream conversion + grouped kernels vs the CPU oracle's reference formulation."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
+    torch.manual_seed(11)
+    F, I, B = 2094, 1174, 512
+    m = AttentionNCF(item_dim=F, item_emb=128, user_emb=128, att_dense=128, mlp_dense_layers=[256, 128]).eval()
+    g = torch.Generator().manual_seed(12)
+    rated = (torch.rand(I, F, generator=g) < 0.02).float() + torch.rand(I, F, generator=g) * 0.1
+    cand = (torch.rand(B, F, generator=g) < 0.02).float() + torch.rand(B, F, generator=g) * 0.1
+    um, _ = _dense_batch(gpu, B, I, 64, 0.125, seed=13)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    sub = slice(0, 48)
+    ref = O.attention_ncf_forward(state, cand[sub], rated, um.cpu()[sub])
+    m = m.to(gpu)
+    with torch.no_grad():
+        out = m(cand.to(gpu), rated.to(gpu), um)
+    assert_close(out[sub], ref)
