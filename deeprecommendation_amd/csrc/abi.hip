@@ -41,6 +41,13 @@ static const struct {
 extern "C" int ncf_version(void) { return NCF_ABI_VERSION; }
 extern "C" const char* ncf_last_error(void) { return ncf::g_err; }
 extern "C" const char* ncf_build_arch(void) { return "gfx950"; }
+#ifndef NCF_BUILD_ID
+#define NCF_BUILD_ID "unstamped"
+#endif
+// hash of every source, header and compiler flag this library was built from (csrc/build.py source_id()); the marker in front lets
+// the build script read it out of the file without loading it
+static const char kBuildId[] = "NCF_BUILD_ID=" NCF_BUILD_ID;
+extern "C" const char* ncf_build_id(void) { return kBuildId + 13; }
 
 extern "C" int ncf_set_option(const char* name, int value) {
     if (!name) return fail(NCF_EINVAL, "ncf_set_option: null name");

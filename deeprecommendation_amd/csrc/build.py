@@ -30,34 +30,83 @@ def sources():
     return [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
 
 
+BASE_FLAGS = ["-O3", "-fPIC", "-std=c++17"]
+
+
+def dependencies():
+    import glob
+    return sources() + sorted(glob.glob(os.path.join(HERE, "*.h"))) + [os.path.join(PKG, "..", "include", "ncf_abi.h")]
+
+
+def source_id() -> str:
+    """16 hex digits over everything the library is built from: every source and header (content, by name), the compiler flags and
+    the target.  Embedded in the library (ncf_build_id()); a library with another id is stale, whatever its mtime says."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(("|".join([ARCH] + BASE_FLAGS) + "|" + repr(sorted(EXTRA_FLAGS.items()))).encode())
+    for f in dependencies():
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def library_id(path=LIB):
+    """The id embedded in a built library, read from the file (no dlopen); None if absent / unstamped."""
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return None
+    k = data.find(b"NCF_BUILD_ID=")
+    if k < 0:
+        return None
+    v = data[k + 13:k + 13 + 16]
+    return v.decode("ascii", "replace") if len(v) == 16 and all(c in b"0123456789abcdef" for c in v) else None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(HERE, "ncf_common.h"), os.path.join(HERE, "mlp_bf16.h"), os.path.join(HERE, "attn_util.h"), os.path.join(HERE, "group_pairs.h"), os.path.join(PKG, "..", "include", "ncf_abi.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return library_id() != source_id()
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
+    sid = source_id()
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    import hashlib
+    headers = [f for f in dependencies() if f.endswith(".h")]
+    hdr = hashlib.sha256(b"".join(open(f, "rb").read() for f in headers)).hexdigest()
+    stamps = {}
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        cmd = [_hipcc(), f"--offload-arch={ARCH}"] + BASE_FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        if os.path.basename(src) == "abi.hip":
+            cmd.insert(-4, f'-DNCF_BUILD_ID="{sid}"')
+        # an object is reused when its source, the headers and its command line are what they were when it was compiled
+        stamp = hashlib.sha256((hdr + " ".join(cmd)).encode() + open(src, "rb").read()).hexdigest()
+        stamps[obj] = stamp
+        try:
+            fresh = not force and os.path.exists(obj) and open(obj + ".id").read() == stamp
+        except OSError:
+            fresh = False
+        if fresh:
+            continue
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
+        procs.append((src, obj, subprocess.Popen(cmd)))
+    for src, obj, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+        open(obj + ".id", "w").write(stamps[obj])
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if library_id() != sid:
+        raise RuntimeError(f"built {LIB} does not carry the id of its sources ({library_id()} != {sid})")
     return LIB
 
 

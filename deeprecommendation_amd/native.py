@@ -31,6 +31,7 @@ SIGNATURES = {
     "ncf_version": (_c_int, []),
     "ncf_last_error": (ctypes.c_char_p, []),
     "ncf_build_arch": (ctypes.c_char_p, []),
+    "ncf_build_id": (ctypes.c_char_p, []),
     "ncf_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
     "ncf_get_option": (_c_int, [ctypes.c_char_p, _c_p]),
     "ncf_bucket_ids": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
@@ -122,9 +123,24 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     if path is None:
+        if not os.environ.get("NCF_HIP_LIBRARY"):        # an A/B build named by the override is loaded as it is
+            _check_build_id(lib, p)
         _lib = lib
         _options_from_environment(lib)
     return lib
+
+
+def _check_build_id(lib, path):
+    """A library built from other sources than the ones next to it is refused (mtime said nothing about a checkout or a copy)."""
+    try:
+        from .csrc import build as _build
+        want = _build.source_id()
+    except (ImportError, OSError):        # sources not shipped: nothing to compare with
+        return
+    have = lib.ncf_build_id().decode()
+    if have != want:
+        raise RuntimeError(f"{path} is stale: built from sources {have}, the sources here are {want}. "
+                           "Rebuild: python -m deeprecommendation_amd.csrc.build")
 
 
 # ncf_set_option values by name (include/ncf_abi.h); 0 / "auto" = choose by shape

@@ -52,6 +52,9 @@ int ncf_version(void);
 const char* ncf_last_error(void);
 /* Architecture the device code was compiled for ("gfx950"). */
 const char* ncf_build_arch(void);
+/* Hash (16 hex digits) of the sources, headers and compiler flags this library was built from — csrc/build.py:source_id().  The
+ * Python binding and __graft_entry__.build() refuse a library whose id differs from the sources next to it (a stale .so). */
+const char* ncf_build_id(void);
 
 /* Process-wide kernel-selection overrides for A/B measurements and for tests that must drive every kernel variant
  * (no counterpart upstream).  0 always means "choose by shape and size" (the default).  Options:

@@ -62,3 +62,17 @@ def test_option_table_matches_the_binding():
     finally:
         for name in native.OPTION_VALUES:
             native.set_option(name, "auto")
+
+
+def test_library_carries_the_id_of_its_sources_and_a_stale_one_is_refused(tmp_path, monkeypatch):
+    """ncf_build_id(): the library embeds a hash of every source / header / flag it was built from; needs_build() compares ids (not
+    mtimes), and the binding refuses a library whose id is not that of the sources next to it."""
+    from deeprecommendation_amd import native
+    from deeprecommendation_amd.csrc import build as b
+    lib = native.load_library()
+    assert lib.ncf_build_id().decode() == b.source_id() == b.library_id()
+    assert not b.needs_build()
+    monkeypatch.setattr(b, "source_id", lambda: "0123456789abcdef")       # as if a source had been edited
+    assert b.needs_build()
+    with pytest.raises(RuntimeError, match="stale"):
+        native._check_build_id(lib, "libncf_hip.so")

@@ -36,7 +36,8 @@ def test_attention_golden(gpu, name):
                  torch.from_numpy(a["user_matrix"]).to(gpu))
     assert_close(out, torch.from_numpy(a["out"]))
     assert_close(att, torch.from_numpy(a["att"]))
-    assert torch.equal(out, out2)
+    assert_close(out2, torch.from_numpy(a["out"]))          # the plain call converts the dense matrix on the stream and may take other
+    assert_close(out, out2, rtol=2e-6)                      # kernels than the call that returns weights: equal to fp32 rounding
     if name.startswith("g3_att_vec"):
         return
     assert float(att[1].abs().sum()) == 0.0   # user without ratings: zeros, not NaN (attention_ncf.py:208-209)
