@@ -355,6 +355,36 @@ def run_cfg2(args, ctx):
             "mlp_256_only": {"fused_us_per_launch": h256_us, "fused_pairs_per_s": B / (h256_us * 1e-6),
                              "flop_per_pair": flop256, "frac_of_fp32_mfma_peak": flop256 * B / (h256_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS},
         }
+        # ---- north_star's ">= 50 % MFMA utilisation on the MLP at emb_dim = 128", in fp32: the same kernel's K0 = 256 instance on
+        # 1 M x 128 and 100 k x 128 fp32 tables (512 MB + 51 MB), MLP 256-256-128-1 — 196 864 FLOP and 1044 B per pair ----
+        try:
+            E2 = 128
+            g3 = torch.Generator(device=device).manual_seed(11)
+            tu2 = torch.empty((U, E2), device=device).normal_(0.0, 0.05, generator=g3)
+            ti2 = torch.empty((I, E2), device=device).normal_(0.0, 0.05, generator=g3)
+            w0 = (torch.rand((HIDDEN[0], 2 * E2), device=device, generator=g3) * 2 - 1) / (2 * E2) ** 0.5
+            packed128 = native.PackedMLP([w0, lin[1].weight, lin[2].weight], [lin[0].bias, lin[1].bias, lin[2].bias])
+            e128_us = back_to_back_us(lambda: native.score_fused(tu2, batches[1][0], ti2, batches[1][1], packed128, out=outbuf))
+            flop128 = 2 * (2 * E2 * HIDDEN[0] + HIDDEN[0] * HIDDEN[1] + HIDDEN[1])
+            dig128 = profile_digest("ncf::score_fused_f32_kernel<256, 256, 128>", "cfg2_emb128") or {}
+            variants["emb128_fp32"] = {"kernel": "score_fused_f32_kernel<256,256,128>", "bound": "mfma", "us_per_launch": e128_us,
+                                       "pairs_per_s": B / (e128_us * 1e-6), "flop_per_pair": flop128, "bytes_per_pair": 2 * E2 * 4 + 16 + 4,
+                                       "achieved": flop128 * B / (e128_us * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": flop128 * B / (e128_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                       "rocprof_avg_us": dig128.get("rocprof_avg_us"), "profile": dig128.get("profile"), "traffic": dig128.get("traffic")}
+            del tu2, ti2, packed128
+        except Exception as exc:  # noqa: BLE001
+            variants["emb128_fp32"] = {"error": f"{type(exc).__name__}: {exc}"}
+        # ---- what the chip delivers for the standalone gather's two access patterns, measured now (library probes): a streaming
+        # copy of the same volume and random 256-byte row reads of the user table ----
+        try:
+            ceil = native.probe_gather_ceilings(tu, batches[2][0], copy_bytes=B * 2 * E * 4)
+            ceil["gather_frac_of_copy_ceiling"] = gather_gbs / ceil["copy"]["GBps"]
+            ceil["note"] = ("the gather reads 2 random 256-byte rows and writes 512 contiguous bytes per pair; a streaming copy of the same bytes is "
+                            "the most this chip moves for that volume, random 256-byte row reads (read bytes only) what the access pattern allows")
+            variants["gather_measured_ceilings"] = ceil
+        except Exception as exc:  # noqa: BLE001
+            variants["gather_measured_ceilings"] = {"error": f"{type(exc).__name__}: {exc}"}
         # opt-in variant (BasicNCF.set_fold_first_layer): layer 1 folded into 256-wide tables; reported beside the default
         # line, never as `value` (its results agree with the oracle to 1e-5 but are not bit-identical to the default kernel's)
         if fold_info is None and native.folded_supported(HIDDEN[0], HIDDEN[1]):
@@ -406,7 +436,8 @@ def run_cfg2(args, ctx):
                             "us_back_to_back": kt_g["us_back_to_back"], "us_isolated_events": kt_g["us_isolated_events"],
                             "rocprof_avg_us": kt_g["rocprof_avg_us"], "profile": kt_g["profile"], "profile_check": kt_g["profile_check"],
                             "ids": "Zipf(1.05) users" if ctxname == "cfg2zipf" else "uniform",
-                            "algorithmic_bytes_per_pair": GATHER_BYTES_PER_PAIR, "algorithmic_bytes_per_launch": GATHER_BYTES_PER_PAIR * B},
+                            "algorithmic_bytes_per_pair": GATHER_BYTES_PER_PAIR, "algorithmic_bytes_per_launch": GATHER_BYTES_PER_PAIR * B,
+                            "frac_of_measured_copy_ceiling": ((variants or {}).get("gather_measured_ceilings") or {}).get("gather_frac_of_copy_ceiling")},
     }
     if variants is not None:
         line["variants"] = variants
@@ -493,7 +524,7 @@ def main():
                     help="opt-in: fold the first MLP layer into the tables (BasicNCF.set_fold_first_layer); NOT the default line")
     ap.add_argument("--no-variants", action="store_true", help="cfg2: skip the variants block (profiling runs: one id distribution per run)")
     ap.add_argument("--zipf-users", action="store_true", help="cfg2: Zipf(1.05) user ids instead of uniform ones (its own profile context)")
-    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5", "train2"],
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg2_emb128", "cfg3", "cfg4", "cfg5", "train2"],
                     help="one config alone (cfg2 = the headline line without other_configs); default: headline + other_configs")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ:

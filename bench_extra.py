@@ -673,6 +673,22 @@ def run_cfg5(args, ctx):
                          "algorithmic_bytes_per_launch": 532 * B, "hbm_GBps_at_this_rate": 532 * B / (us * 1e-6) / 1e9,
                          "rocprof_avg_us": kt["rocprof_avg_us"], "profile": kt["profile"], "profile_check": kt["profile_check"]},
             "variants": big_variants}
+    if world == 1 and big:
+        # What "2.5 PFLOP/s" is worth on THIS chip, now: the bf16 MFMA rate it sustains on random operands (it lowers its clock under
+        # matrix load), measured by the library's probe kernel in this process — and every bf16 figure of the line as a fraction of it.
+        try:
+            pr = native.probe_mfma_bf16(device, seconds=2.0)
+            prl = native.probe_mfma_bf16(device, seconds=1.0, with_lds=True)
+            rl = line["roofline"]
+            rl["sustained_mfma_probe"] = {"TFLOPs": pr["TFLOPs"], "clock_GHz": pr["clock_GHz"], "cycles_per_mfma_per_simd": pr["cycles_per_mfma_per_simd"],
+                                          "with_lds_operand_reads": {"TFLOPs": prl["TFLOPs"], "clock_GHz": prl["clock_GHz"]},
+                                          "what": pr["mfma"] + f", {pr['launches']} back-to-back launches of {pr['us_per_launch'] / 1e3:.2f} ms, the last 4 timed",
+                                          "frac_of_spec_peak": pr["TFLOPs"] / bench.PEAK_BF16_MFMA_TFLOPS}
+            rl["frac_of_sustained_mfma"] = tf / pr["TFLOPs"]
+            for bv in big_variants.values():
+                bv["frac_of_sustained_mfma"] = bv["achieved_TFLOPs"] / pr["TFLOPs"]
+        except Exception as exc:  # noqa: BLE001 — calibration must never cost the line
+            line["roofline"]["sustained_mfma_probe"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world == 1 and not getattr(args, "no_cpu_baseline", False):
         line["cpu_baseline"] = _cfg5_cpu_baseline(ws, bs, E, B)
     return line
@@ -734,5 +750,48 @@ def run_train2(args, ctx):
                                "forward / dgrad / wgrad / bias-grad / ReLU mask"}}
 
 
+# ---------------------------------------------------------------------------------------------------- cfg 2 at emb_dim = 128, fp32
+def run_cfg2_emb128(args, ctx):
+    """north_star's "MFMA utilisation on the MLP at emb_dim = 128" in fp32 (its own rocprofv3 context): BasicNCF 1 M x 100 k tables of
+    128 fp32 columns (512 MB + 51 MB), MLP 256-256-128-1, batch 65 536 — the K0 = 256 instance of the fused kernel."""
+    import bench
+    from deeprecommendation_amd import native
+    device = ctx.device
+    U, I, E, B, H = bench.U, bench.I, 128, bench.B, bench.HIDDEN
+    g = torch.Generator(device=device).manual_seed(11)
+    tu = torch.empty((U, E), device=device).normal_(0.0, 0.05, generator=g)
+    ti = torch.empty((I, E), device=device).normal_(0.0, 0.05, generator=g)
+    dims = [2 * E, H[0], H[1], 1]
+    ws = [(torch.rand((dims[k + 1], dims[k]), device=device, generator=g) * 2 - 1) / dims[k] ** 0.5 for k in range(3)]
+    bs = [(torch.rand((dims[k + 1],), device=device, generator=g) * 2 - 1) / dims[k] ** 0.5 for k in range(3)]
+    packed = native.PackedMLP(ws, bs)
+    batches = [(torch.randint(0, U, (B,), device=device, generator=g), torch.randint(0, I, (B,), device=device, generator=g)) for _ in range(8)]
+    out = torch.empty((B, 1), device=device)
+
+    def step(k):
+        return native.score_fused(tu, batches[k % 8][0], ti, batches[k % 8][1], packed, out=out)
+
+    wall, warm = _time_steps(step, args.warmup, args.steps)
+    cyc = [0]
+
+    def fused():
+        cyc[0] = (cyc[0] + 1) % 8
+        native.score_fused(tu, batches[cyc[0]][0], ti, batches[cyc[0]][1], packed, out=out)
+
+    kt = bench.kernel_time("ncf::score_fused_f32_kernel<256, 256, 128>", "cfg2_emb128", fused)
+    flop = 2 * (2 * E * H[0] + H[0] * H[1] + H[1])
+    tf = flop * B / (kt["us"] * 1e-6) / 1e12
+    return {"metric": "scored user-item pairs/sec", "value": B * args.steps / wall, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": warm, "warmup_requested": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2 at emb_dim=128: BasicNCF {U} users x {I} items, emb_dim={E} fp32, batch={B}, MLP 256-256-128-1 (kernel calls, no model wrapper)"},
+            "roofline": {"kernel": "score_fused_f32_kernel<256,256,128>", "bound": "mfma", "achieved": tf, "peak": bench.PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf / bench.PEAK_F32_MFMA_TFLOPS, "traffic": kt["traffic"], "us_per_launch": kt["us"],
+                         "us_per_launch_basis": kt["basis"], "us_back_to_back": kt["us_back_to_back"], "rocprof_avg_us": kt["rocprof_avg_us"],
+                         "profile": kt["profile"], "profile_check": kt["profile_check"],
+                         "algorithmic_flop_per_pair": flop, "algorithmic_bytes_per_pair": 2 * E * 4 + 16 + 4,
+                         "algorithmic_bytes_per_launch": (2 * E * 4 + 16 + 4) * B}}
+
+
 # name -> (function, (default steps, default warm-up))
-WORKLOADS = {"cfg3": (run_cfg3, (50, 5)), "cfg4": (run_cfg4, (5, 1)), "cfg5": (run_cfg5, (100, 10)), "train2": (run_train2, (20, 3))}
+WORKLOADS = {"cfg2_emb128": (run_cfg2_emb128, (200, 300)), "cfg3": (run_cfg3, (50, 5)), "cfg4": (run_cfg4, (5, 1)), "cfg5": (run_cfg5, (100, 10)), "train2": (run_train2, (20, 3))}

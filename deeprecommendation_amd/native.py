@@ -32,6 +32,9 @@ SIGNATURES = {
     "ncf_last_error": (ctypes.c_char_p, []),
     "ncf_build_arch": (ctypes.c_char_p, []),
     "ncf_build_id": (ctypes.c_char_p, []),
+    "ncf_probe_mfma_bf16": (_c_int, [_c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
+    "ncf_probe_copy": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
+    "ncf_probe_gather_read": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_p]),
     "ncf_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
     "ncf_get_option": (_c_int, [ctypes.c_char_p, _c_p]),
     "ncf_bucket_ids": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
@@ -690,6 +693,84 @@ def dense_to_csr(user_matrix: torch.Tensor, share_rows: bool = True):
     torch.cumsum(keep, 0, out=rowptr[1:])
     _check(lib.ncf_dense_csr_fill(_ptr(user_matrix), ld, B, I, _ptr(rowptr), _ptr(pair_row), _ptr(col), _ptr(val), _stream(user_matrix)))
     return rowptr, col, val, pair_row
+
+
+def _events_us(fn, reps, settle):
+    for _ in range(settle):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def probe_gather_ceilings(table: torch.Tensor, idx: torch.Tensor, copy_bytes: int, reps: int = 100):
+    """What the chip delivers, now, for the two patterns the standalone gather is made of (ncf_probe_copy / ncf_probe_gather_read):
+    a streaming copy of ``copy_bytes`` (read + write counted) and random whole-row reads of ``table`` rows named by ``idx`` (read
+    bytes only) at 1 / 2 / 4 / 8 rows in flight per lane group and two grid sizes.  GB/s; the best of the sweep is the ceiling."""
+    lib = load_library()
+    _dev(table, "table")
+    rows, E, ld = _rows2d(table, "table")
+    rb = E * table.element_size()
+    dev = table.device
+    st = torch.cuda.current_stream(dev).cuda_stream
+    src = torch.empty(copy_bytes, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    us = _events_us(lambda: _check(lib.ncf_probe_copy(_ptr(src), _ptr(dst), copy_bytes, st)), reps, 30)
+    out = {"copy": {"bytes_read_plus_written": 2 * copy_bytes, "us": us, "GBps": 2 * copy_bytes / (us * 1e-6) / 1e9}, "random_row_read": {}}
+    n = idx.numel()
+    best = 0.0
+    for blocks in (2048, 8192):
+        sink = torch.empty(blocks * 256, dtype=torch.int32, device=dev)
+        for u in (1, 2, 4, 8):
+            us = _events_us(lambda: _check(lib.ncf_probe_gather_read(_ptr(table), rows, ld * table.element_size(), rb, _ptr(idx), n, u, blocks,
+                                                                     _ptr(sink), st)), reps, 20)
+            gbs = n * rb / (us * 1e-6) / 1e9
+            out["random_row_read"][f"blocks{blocks}_inflight{u}"] = {"us": us, "GBps": gbs}
+            best = max(best, gbs)
+    out["random_row_read_best_GBps"] = best
+    out["row_bytes"] = rb
+    return out
+
+
+def probe_mfma_bf16(device, seconds: float = 2.0, with_lds: bool = False, blocks: int = 256, iters: int = 20000):
+    """The bf16 MFMA rate the chip sustains on random operands (ncf_probe_mfma_bf16): back-to-back launches for ``seconds`` (the
+    clock needs about two seconds of load to settle), the LAST launches timed with HIP events.  Returns {"TFLOPs", "clock_GHz",
+    "us_per_launch", ...}."""
+    lib = load_library()
+    g = torch.Generator(device=device).manual_seed(1234)
+    rnd = (torch.randn(32768, device=device, generator=g) * 0.5).to(torch.bfloat16).contiguous()      # 64 KiB of finite bf16
+    sink = torch.empty(blocks * 512, dtype=torch.float32, device=device)
+    clk = torch.zeros(blocks * 8 * 2, dtype=torch.int64, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def launch():
+        _check(lib.ncf_probe_mfma_bf16(_ptr(rnd), int(iters), int(blocks), 1 if with_lds else 0, _ptr(sink), _ptr(clk), stream))
+
+    flop = blocks * 8 * iters * 32 * 16384
+    launch()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); launch(); e1.record()
+    torch.cuda.synchronize(device)
+    one = e0.elapsed_time(e1) * 1e-3
+    n = max(4, int(seconds / max(one, 1e-6)))
+    for _ in range(n - 4):
+        launch()
+    e0.record()
+    for _ in range(4):
+        launch()
+    e1.record()
+    torch.cuda.synchronize(device)
+    us = e0.elapsed_time(e1) * 1e3 / 4
+    c = clk.view(-1, 2).double().cpu()
+    ghz = float((c[:, 0] / c[:, 1].clamp_min(1)).median()) * 0.1
+    return {"TFLOPs": flop / (us * 1e-6) / 1e12, "clock_GHz": ghz, "us_per_launch": us, "launches": n, "blocks": blocks,
+            "iters": iters, "with_lds_reads": bool(with_lds), "mfma": "v_mfma_f32_16x16x32_bf16, 2 waves per SIMD, register operands, random data",
+            "cycles_per_mfma_per_simd": float(c[:, 0].median()) / (iters * 32 * 2)}      # two waves share a SIMD's matrix pipe
 
 
 def attn_candidates_supported(K: int, N1: int, N2: int) -> bool:

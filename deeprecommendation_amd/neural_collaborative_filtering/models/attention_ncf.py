@@ -132,14 +132,16 @@ class SparseRatings:
                              user_matrix.shape[1])
 
     @staticmethod
-    def from_dense_on_stream(user_matrix: torch.Tensor) -> "SparseRatings":
+    def from_dense_on_stream(user_matrix: torch.Tensor, share_identical_rows: bool = True) -> "SparseRatings":
         """``from_dense`` without a single host read (libncf_hip.so: ncf_dense_csr_rows + a cumulative sum + ncf_dense_csr_fill, all
         on the current stream): rows that are exactly equal share one CSR row — found by a row hash, VERIFIED element by element on
         the device.  The CSR keeps B rows (a row that shares another's is empty) and ``col`` / ``val`` are sized for the worst case
         B * I, of which rowptr[B] entries are valid: sizes the host never learns.  What the host cannot know either is how much
         sharing there is; the reference's callers repeat rows (datasets/dynamic_datasets.py:24-40, webapp/backend.py:78-121), so the
         result carries ``pairs_per_row_hint`` = the grouped kernels' threshold: they are correct for any amount of sharing."""
-        rowptr, col, val, pair_row = native.dense_to_csr(user_matrix.contiguous())
+        rowptr, col, val, pair_row = native.dense_to_csr(user_matrix.contiguous(), share_identical_rows)
+        if not share_identical_rows:             # one CSR row per pair (the per-pair kernel's input): no indirection
+            return SparseRatings(rowptr, col, val, user_matrix.shape[1])
         r = SparseRatings(rowptr, col, val, user_matrix.shape[1], pair_row=pair_row,
                           pairs_per_row_hint=SparseRatings.GROUPED_MIN_PAIRS_PER_ROW)
         r.nnz_hint = max(1, user_matrix.shape[1] // 4) * user_matrix.shape[0]     # for launch geometry only (slices per rated set)
@@ -237,19 +239,20 @@ class AttentionNCF(_ScoringMixin, NCF):
         li, lu = self.ItemEmbeddings[0], self.UserEmbeddings[0]
         rated_emb, pr, proj = self.precompute_catalog(rated_items, cache)
         pc_kept = None
+        att_dense = 0 if self.use_cos_sim_instead else int(self.att_dense or 0)
+        A_att = li.out_features if self.use_cos_sim_instead else (att_dense or 1)
+        mode_att = native.ATT_COS if self.use_cos_sim_instead else (native.ATT_MLP_SCALED if att_dense else native.ATT_LINEAR)
+        can_group = native.attn_grouped_supported(mode_att, A_att, lu.out_features)
         if isinstance(user_matrix, SparseRatings):
             ratings = user_matrix
         elif (user_matrix.is_cuda and user_matrix.dtype == torch.float32 and not return_attention_weights
               and 0 < user_matrix.numel() <= native.DENSE_CSR_MAX_ENTRIES and self.dense_user_matrix_on_stream):
-            ratings = SparseRatings.from_dense_on_stream(user_matrix)      # the reference's call shape, no host round trip
+            # the reference's call shape, no host round trip; rows are shared only where a grouped kernel can use the sharing
+            ratings = SparseRatings.from_dense_on_stream(user_matrix, share_identical_rows=can_group)
         else:
             ratings = SparseRatings.from_dense(user_matrix)
         shared = ratings.pair_row is not None
-        att_dense = 0 if self.use_cos_sim_instead else int(self.att_dense or 0)
-        A_att = li.out_features if self.use_cos_sim_instead else (att_dense or 1)
-        mode_att = native.ATT_COS if self.use_cos_sim_instead else (native.ATT_MLP_SCALED if att_dense else native.ATT_LINEAR)
-        grouped = (shared and native.attn_grouped_supported(mode_att, A_att, lu.out_features)
-                   and ratings.pairs_per_row >= SparseRatings.GROUPED_MIN_PAIRS_PER_ROW)
+        grouped = shared and can_group and ratings.pairs_per_row >= SparseRatings.GROUPED_MIN_PAIRS_PER_ROW
         grouping = None
         pc = None
         # never inside a HIP-graph capture: a hit would leave the candidate projections out of the captured graph

@@ -463,6 +463,23 @@ int ncf_scatter_add_cols(const float* dev_src, int64_t ld_src, const int64_t* de
 int ncf_adam_step(float* dev_p, const float* dev_g, float* dev_m, float* dev_v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, ncf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Calibration probe — the bf16 MFMA rate the chip SUSTAINS on random operands (it lowers its clock under matrix load), so that
+ * bench.py can state a kernel's fraction of it next to the fraction of the 2.5 PFLOP/s datasheet figure.  Not part of scoring.
+ * Launches `blocks` 512-thread workgroups; every wave issues iters * 32 v_mfma_f32_16x16x32_bf16 (16 384 flop each) on register
+ * operands taken from dev_rnd (64 KiB of random bf16 bit patterns, finite values); with_lds != 0 adds the scoring kernels' LDS
+ * operand reads.  dev_sink: blocks * 512 floats (written, never meaningful); dev_clk: blocks * 8 pairs of u64
+ * {shader cycles, 100 MHz ticks} per wave.  flop per launch = blocks * 8 * iters * 32 * 16384.
+ * ------------------------------------------------------------------------------------------------ */
+int ncf_probe_mfma_bf16(const void* dev_rnd, int iters, int blocks, int with_lds, float* dev_sink, unsigned long long* dev_clk,
+                        ncf_stream_t stream);
+/* Memory-side probes for the standalone gather's roofline: a streaming 16-byte copy of `bytes` (the chip's copy ceiling), and
+ * random whole-row READS (rows of row_bytes = 16 .. 1024, a power of two; ids from dev_idx, n of them; `inflight` = 1 / 2 / 4 / 8
+ * independent rows per lane group; nothing is written but one word per thread into dev_sink (blocks * 256 words)). */
+int ncf_probe_copy(const void* dev_src, void* dev_dst, int64_t bytes, ncf_stream_t stream);
+int ncf_probe_gather_read(const void* dev_table, int64_t rows, int64_t ld_bytes, int row_bytes, const int64_t* dev_idx, int64_t n,
+                          int inflight, int blocks, uint32_t* dev_sink, ncf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
