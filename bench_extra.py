@@ -67,12 +67,12 @@ def _cfg4_graph(device):
                      user2item_edge_attr=attr, item2user_edge_attr=attr.clone(), num_items=I, num_users=U)
 
 
-def _cfg4_model(device, L=3, D=128):
+def _cfg4_model(device, L=3, D=128, conv="LightGCN"):
     from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphNCF
     I, U = 100_000, 1_000_000
     torch.manual_seed(1234)
     with torch.device("meta"):
-        model = GraphNCF(item_dim=I, user_dim=U, num_gnn_layers=L, hetero=True, node_emb=D, mlp_dense_layers=[256, 128])
+        model = GraphNCF(item_dim=I, user_dim=U, num_gnn_layers=L, hetero=True, node_emb=D, mlp_dense_layers=[256, 128], convType=conv)
     model = model.to_empty(device=device).eval()
     gg = torch.Generator(device=device).manual_seed(1234)  # the same weights on every rank
     with torch.no_grad():
@@ -167,6 +167,31 @@ def run_cfg4(args, ctx):
                          "hoisted_gemm_us": gemm_us,
                          "note": "the algorithmic rate (520 B per edge) can exceed the HBM peak: the 51 MB of item rows — half of all source "
                                  "reads — are served by the Infinity Cache and never reach HBM; what did is the counter figure"}}
+    if not getattr(args, "no_variants", False):
+        # LightGAT (gnn_ncf.py:97-177) on the same graph: per layer one GEMV for the source scores, the per-destination edge softmax
+        # (two passes over 4-byte scalars per row) and the same SpMM with the softmax as its coefficients
+        try:
+            from deeprecommendation_amd import native
+            gat = _cfg4_model(device, L, D, conv="LightGAT")
+
+            def gstep(k):
+                gat._native_cache = {}
+                gat._native_ver = None
+                with torch.no_grad():
+                    return gat.propagate_all(graph)
+
+            wall_g, warm_g = _time_steps(gstep, args.warmup, args.steps)
+            sv = torch.randn(N, device=device)
+            sm_us = bench.back_to_back_us(lambda: native.edge_softmax_csr(prep.rowptr, prep.col, prep.attr, sv), reps=10, settle=3)
+            sm_bytes = E * (4 + 4 + 4 + 4 + 4) + N * 16       # col + attr read, gathered score twice, coefficient written
+            line["variants"] = {"lightgat": {"edges_per_s": L * E * args.steps / wall_g, "ms_per_step": wall_g / args.steps * 1e3,
+                                             "vs_lightgcn": wall / wall_g, "edge_softmax_us_per_layer": sm_us,
+                                             "edge_softmax_GBps_algorithmic": sm_bytes / (sm_us * 1e-6) / 1e9,
+                                             "edge_softmax_frac_of_hbm_peak": sm_bytes / (sm_us * 1e-6) / 1e9 / bench.PEAK_HBM_GBS,
+                                             "note": "same SpMM kernel with per-layer coefficients; the softmax passes are the added cost"}}
+            del gat, sv
+        except Exception as exc:  # noqa: BLE001
+            line["variants"] = {"lightgat": {"error": f"{type(exc).__name__}: {exc}"}}
     if not getattr(args, "no_cpu_baseline", False):
         line["cpu_baseline"] = _cfg4_cpu_baseline(model, D)
     return line

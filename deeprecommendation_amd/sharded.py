@@ -499,15 +499,20 @@ class PartitionedLightGCN:
                   sums are identical to the single-GPU kernel's -> bitwise equal results.
     mode "edge" : rank r owns edges r::W of every destination row and the full node table; per layer: hoisted
                   Linear (replicated), local SpMM -> partial (N, D), all-reduce(sum).  BASELINE's named form.
+    LightGAT (gnn_ncf.py:97-177; mode "dst" only: the per-destination softmax needs all in-edges of a row on one rank): the
+    source scores s[n] = w_j . x[n] travel WITH the Z blocks — the exchanged buffer is (N, D + 4), Z in columns [0, D) and s in
+    column D — and every rank turns its rows' scores into edge coefficients (ncf_edge_softmax_csr) before its SpMM.
     ``spmm`` / ``linear`` default to the HIP library; the gloo tests pass torch stand-ins.
     """
 
     def __init__(self, model, graph, mode="dst", group=None, local_ops=None):
         if mode not in ("dst", "edge"):
             raise ValueError("mode must be 'dst' or 'edge'")
-        if getattr(model, "convType", "LightGCN") != "LightGCN" or getattr(model, "concat", False):
-            raise NotImplementedError("PartitionedLightGCN propagates LightGCN layers with the mean readout "
-                                      "(convType='LightGCN', concat=False); LightGAT / concat are single-GPU only")
+        self.gat = getattr(model, "convType", "LightGCN") == "LightGAT"
+        if getattr(model, "convType", "LightGCN") not in ("LightGCN", "LightGAT") or getattr(model, "concat", False):
+            raise NotImplementedError("PartitionedLightGCN propagates LightGCN / LightGAT layers with the mean readout (concat=False)")
+        if self.gat and mode != "dst":
+            raise NotImplementedError("LightGAT needs all in-edges of a destination on one rank (its softmax runs over them): mode='dst' only")
         self.model, self.mode, self.group = model, mode, group
         self.comm = Comm(group)
         self.world, self.rank = self.comm.world, self.comm.rank
@@ -545,8 +550,16 @@ class PartitionedLightGCN:
                 src2 = i2u[0] + N
         src = torch.cat([u2i[0], src2])
         coef = torch.cat([c1, c2])
+        a1, a2 = graph.user2item_edge_attr, graph.item2user_edge_attr
+        attr = None                                   # LightGAT: the raw edge weights (weight * alpha, no degree norm, gnn_ncf.py:173-176)
+        if self.gat and a1 is not None and a2 is not None:
+            attr = torch.cat([a1, a2]).to(torch.float32)
+        if self.gat and hetero and self.stacked:
+            raise NotImplementedError("LightGAT on a hetero graph whose destinations mix edge types is single-GPU / torch only")
         order = torch.argsort(dst, stable=True)
         src, dst, coef = src[order], dst[order], coef[order]
+        if attr is not None:
+            attr = attr[order]
         del order
         rowptr = torch.zeros(N + 1, dtype=torch.int64, device=dst.device)
         rowptr[1:] = torch.cumsum(counts, 0)
@@ -563,6 +576,7 @@ class PartitionedLightGCN:
             self.lo, self.hi = lo, hi
             self.col = src[e0:e1].to(torch.int32).contiguous()
             self.coef = coef[e0:e1].contiguous()
+            self.attr = None if attr is None else attr[e0:e1].contiguous()
             self.rowptr = (rowptr[lo:hi + 1] - e0).contiguous()
         else:
             keep = (torch.arange(E, device=dst.device) % W) == r
@@ -621,10 +635,61 @@ class PartitionedLightGCN:
             self._linear(x_rows[split:], conv.user2item_W[0], out=out[split:])
         return out
 
+    def _score_rows(self, x_rows, lo, hi, out):
+        """LightGAT source scores s[n] = w_j . x[n] for global rows [lo, hi) (the destination half of AttNet and its bias are
+        constant inside a destination's softmax and cancel, models/gnn_ncf.py LightGATConv) into ``out`` ((hi - lo, 1), strided)."""
+        conv = self.model.gnn_convs[0]
+        D = x_rows.shape[1]
+        if hi <= lo:
+            return out
+
+        def gemv(x, att, o):
+            w = att[0].weight.detach()[:, :D].contiguous()
+            if self.ops is None:
+                return native.linear(x.contiguous(), w, None, out=o)
+            o.copy_(self.ops.linear(x, w, None))
+            return o
+        if not conv.hetero:
+            return gemv(x_rows, conv.AttNet, out)
+        split = min(max(self.I - lo, 0), hi - lo)          # items are the sources of item->user edges, users of user->item edges
+        if split > 0:
+            gemv(x_rows[:split], conv.item2user_AttNet, out[:split])
+        if split < hi - lo:
+            gemv(x_rows[split:], conv.user2item_AttNet, out[split:])
+        return out
+
+    def _edge_softmax(self, s):
+        if self.ops is None:
+            return native.edge_softmax_csr(self.rowptr, self.col, self.attr, s)
+        return self.ops.edge_softmax(self.rowptr, self.col, self.attr, s)
+
+    def _propagate_gat(self, x0):
+        L = len(self.model.gnn_convs)
+        D = x0.shape[1]
+        lo, hi = self.lo, self.hi
+        x_blk = x0[lo:hi]
+        acc = x_blk.clone()
+        zs = torch.zeros((self.N, D + 4), dtype=torch.float32, device=x0.device)   # Z | s | 3 pad columns (rows stay 16-byte multiples)
+        for _ in range(L):
+            self._hoist_rows(x_blk, lo, hi, zs[lo:hi, :D])
+            self._score_rows(x_blk, lo, hi, zs[lo:hi, D:D + 1])
+            self.comm.exchange_blocks(zs, self.bounds)         # the scores travel with the Z blocks: one exchange per layer
+            coef = self._edge_softmax(zs[:, D].contiguous())
+            if self.ops is None:
+                x_blk = self.csr.spmm(zs[:, :D], acc_sum=acc, coef=coef)
+            else:
+                x_blk = self.ops.spmm(self.rowptr, self.col, coef, zs[:, :D], hi - lo)
+                acc += x_blk
+        out = torch.empty((self.N, D), dtype=torch.float32, device=x0.device)
+        self._mean(acc, L, out=out[lo:hi])
+        return self.comm.exchange_blocks(out, self.bounds)
+
     def propagate(self, x0: torch.Tensor) -> torch.Tensor:
         """x0: full (N, D) initial node table (replicated).  Returns the full mean-combined table (gnn_ncf.py:351)."""
         L = len(self.model.gnn_convs)
         D = x0.shape[1]
+        if self.gat:
+            return self._propagate_gat(x0)
         if self.mode == "dst":
             lo, hi = self.lo, self.hi
             x_blk = x0[lo:hi]

@@ -96,6 +96,15 @@ class TorchOps:
         return torch.zeros((n_rows, z.shape[1])).index_add_(0, dst, coef[:, None] * z[col.long()])
 
     @staticmethod
+    def edge_softmax(rowptr, col, attr, s):
+        """ncf_edge_softmax_csr restated: per destination row softmax of s[col] (PyG softmax: / (sum + 1e-16)), times the edge weight."""
+        n = rowptr.numel() - 1
+        dst = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+        sc = s[col.long()].view(-1, 1)
+        a = O.pyg_softmax(sc, dst, n).view(-1)
+        return a * attr if attr is not None else a
+
+    @staticmethod
     def coef(graph, N):
         u2i, i2u = graph.user2item_edge_index, graph.item2user_edge_index
         deg = O.pyg_degree(torch.cat([u2i[1], i2u[1]]), N)
@@ -221,7 +230,7 @@ def _sharded_worker(rank, world, store_path, replicate_items, exchange="unique")
         dist.destroy_process_group()
 
 
-def _graph_worker(rank, world, store_path, mode, hetero):
+def _graph_worker(rank, world, store_path, mode, hetero, conv="LightGCN"):
     from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphData, GraphNCF
     from deeprecommendation_amd.sharded import PartitionedLightGCN
     _init(rank, world, store_path)
@@ -235,7 +244,8 @@ def _graph_worker(rank, world, store_path, mode, hetero):
         graph = GraphData(user2item_edge_index=u2i, item2user_edge_index=i2u, user2item_edge_attr=a1, item2user_edge_attr=a2,
                           num_items=n_items, num_users=n_users)
         torch.manual_seed(5)
-        model = GraphNCF(item_dim=n_items, user_dim=n_users, num_gnn_layers=L, hetero=hetero, node_emb=D, mlp_dense_layers=[8]).eval()
+        model = GraphNCF(item_dim=n_items, user_dim=n_users, num_gnn_layers=L, hetero=hetero, node_emb=D, mlp_dense_layers=[8],
+                         convType=conv).eval()
         state = {k: v.clone() for k, v in model.state_dict().items()}
         with torch.no_grad():
             x0 = torch.vstack([model.item_embeddings[0].weight.t() + model.item_embeddings[0].bias,
@@ -246,7 +256,7 @@ def _graph_worker(rank, world, store_path, mode, hetero):
         conv_state = {k[len("gnn_convs.0."):]: v for k, v in state.items() if k.startswith("gnn_convs.0.")}
         hs, x = [x0], x0
         for _ in range(L):
-            x = O.lightgcn_conv(x, conv_state, hetero, u2i, i2u, a1, a2)
+            x = (O.lightgcn_conv if conv == "LightGCN" else O.lightgat_conv)(x, conv_state, hetero, u2i, i2u, a1, a2)
             hs.append(x)
         ref = torch.mean(torch.stack(hs, 0), 0)
         assert combined.shape == ref.shape
@@ -277,10 +287,18 @@ def test_partitioned_lightgcn_rejects_other_convolutions():
     from deeprecommendation_amd.sharded import PartitionedLightGCN
     ei = torch.tensor([[3, 4], [0, 1]])
     graph = GraphData(user2item_edge_index=ei, item2user_edge_index=ei.flip(0), num_items=3, num_users=2)
-    for kw in ({"convType": "LightGAT"}, {"concat": True}):
+    for kw, mode in (({"convType": "LightGAT"}, "edge"), ({"concat": True}, "dst")):   # LightGAT: destination blocks only
         model = GraphNCF(item_dim=3, user_dim=2, num_gnn_layers=1, hetero=False, node_emb=4, mlp_dense_layers=[4], **kw)
         with pytest.raises(NotImplementedError):
-            PartitionedLightGCN(model, graph, local_ops=TorchOps)
+            PartitionedLightGCN(model, graph, mode=mode, local_ops=TorchOps)
+
+
+@pytest.mark.parametrize("hetero", [True, False])
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_lightgat_dst_blocks(hetero, world):
+    """LightGAT (gnn_ncf.py:97-177) over destination blocks: the source scores travel with the Z blocks, every rank runs the
+    per-destination softmax of its own rows; against the oracle's per-edge formulation on the whole graph."""
+    _spawn(_graph_worker, "dst", hetero, "LightGAT", world=world)
 
 
 @pytest.mark.parametrize("mode", ["dst", "edge"])

@@ -133,14 +133,13 @@ def test_degree_and_coef_match_torch(gpu):
     assert torch.allclose(coef.cpu(), ref, rtol=2e-7, atol=0)
 
 
-def test_full_size_lightgcn_properties(gpu):
-    """BASELINE configs[3] at FULL size (1.1 M nodes, D = 128, 50 M interactions = 100 M directed edges, Zipf items —
-    the graph bench.py's cfg-4 workload builds): linearity  SpMM(a z1 + b z2) == a SpMM(z1) + b SpMM(z2)  within fp32 rounding,
-    column checksum sum_n y[n] == sum_e coef_e z[col_e], and bitwise run-to-run determinism."""
-    from deeprecommendation_amd import native
+@pytest.fixture(scope="module")
+def full_graph(gpu):
+    """BASELINE configs[3] at FULL size (the graph bench.py's cfg-4 workload builds): 1 M users + 100 k items, 50 M interactions
+    (user uniform, item Zipf(1.0)) = 100 M directed edges; built once for the full-size tests of this module."""
     from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphData, PreparedGraph
     g = torch.Generator(device=gpu).manual_seed(11)
-    I, U, D, n = 100_000, 1_000_000, 128, 50_000_000
+    I, U, n = 100_000, 1_000_000, 50_000_000
     ranks = torch.arange(1, I + 1, device=gpu, dtype=torch.float64)
     p = (1.0 / ranks)
     items = torch.multinomial((p / p.sum()).float(), n, replacement=True, generator=g)
@@ -149,9 +148,57 @@ def test_full_size_lightgcn_properties(gpu):
     graph = GraphData(user2item_edge_index=torch.stack([users, items]), item2user_edge_index=torch.stack([items, users]),
                       user2item_edge_attr=attr, item2user_edge_attr=attr.clone(), num_items=I, num_users=U)
     prep = PreparedGraph(graph, hetero=True)
+    yield graph, prep, g
+    del graph, prep
+    torch.cuda.empty_cache()
+
+
+def test_full_size_lightgat_properties(gpu, full_graph):
+    """LightGAT's per-destination edge softmax (gnn_ncf.py:158-176; PyG softmax) at FULL cfg-4 size — 100 M edges, hub items with
+    millions of in-edges: the attention weights of every non-empty destination are positive and sum to 1, the edge weight enters as
+    a plain factor, a shift of all scores changes nothing, and the whole layer (scores -> softmax -> SpMM) is bitwise repeatable."""
+    from deeprecommendation_amd import native
+    graph, prep, g = full_graph
+    I, U, D = graph.num_items, graph.num_users, 128
+    N = I + U
+    assert prep.type_pure
+    s = torch.randn(N, device=gpu, generator=g) * 2.0
+    alpha = native.edge_softmax_csr(prep.rowptr, prep.col, None, s)
+    assert alpha.numel() == prep.col.numel() and float(alpha.min()) >= 0.0
+    counts = prep.rowptr[1:] - prep.rowptr[:-1]
+    sums = torch.zeros(N, dtype=torch.float64, device=gpu)
+    step = 10_000_000
+    row_of_edge = torch.repeat_interleave(torch.arange(N, device=gpu), counts)
+    for a in range(0, alpha.numel(), step):
+        sums.index_add_(0, row_of_edge[a:a + step], alpha[a:a + step].double())
+    nonempty = counts > 0
+    err = float((sums[nonempty] - 1.0).abs().max())
+    assert err <= 2e-5, f"attention weights of a destination do not sum to 1: {err:.3e}"      # hub rows add 4 M fp32 terms
+    assert float(sums[~nonempty].abs().max()) == 0.0 if bool((~nonempty).any()) else True
+    del row_of_edge, sums
+    assert torch.equal(alpha, native.edge_softmax_csr(prep.rowptr, prep.col, None, s))            # run to run, bit for bit
+    shifted = native.edge_softmax_csr(prep.rowptr, prep.col, None, s + 3.0)
+    assert float((shifted - alpha).abs().max()) <= 1e-5 * float(alpha.max())
+    del shifted
+    coef = native.edge_softmax_csr(prep.rowptr, prep.col, prep.attr, s)
+    ref = prep.attr * alpha
+    assert float((coef - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    del ref, alpha
+    z = torch.randn(N, D, device=gpu, generator=g)
+    y1 = prep.csr.spmm(z, coef=coef).clone()
+    y2 = prep.csr.spmm(z, coef=coef)
+    assert torch.equal(y1, y2) and bool(torch.isfinite(y1).all())
+
+
+def test_full_size_lightgcn_properties(gpu, full_graph):
+    """BASELINE configs[3] at FULL size (1.1 M nodes, D = 128, 50 M interactions = 100 M directed edges, Zipf items —
+    the graph bench.py's cfg-4 workload builds): linearity  SpMM(a z1 + b z2) == a SpMM(z1) + b SpMM(z2)  within fp32 rounding,
+    column checksum sum_n y[n] == sum_e coef_e z[col_e], and bitwise run-to-run determinism."""
+    from deeprecommendation_amd import native
+    graph, prep, g = full_graph
+    I, U, D, n = graph.num_items, graph.num_users, 128, 50_000_000
     assert prep.row_of is not None and prep.split == I
     assert prep.col.numel() == 2 * n
-    del items, users, attr
     N = I + U
     z1 = torch.randn(N, D, device=gpu, generator=g)
     z2 = torch.randn(N, D, device=gpu, generator=g)
