@@ -182,7 +182,7 @@ def run_cfg4(args, ctx):
 
             wall_g, warm_g = _time_steps(gstep, args.warmup, args.steps)
             sv = torch.randn(N, device=device)
-            sm_us = bench.back_to_back_us(lambda: native.edge_softmax_csr(prep.rowptr, prep.col, prep.attr, sv), reps=10, settle=3)
+            sm_us = bench.back_to_back_us(lambda: native.edge_softmax_csr(prep.rowptr, prep.col, prep.attr, sv, segments=prep.softmax_segments()), reps=10, settle=3)
             sm_bytes = E * (4 + 4 + 4 + 4 + 4) + N * 16       # col + attr read, gathered score twice, coefficient written
             line["variants"] = {"lightgat": {"edges_per_s": L * E * args.steps / wall_g, "ms_per_step": wall_g / args.steps * 1e3,
                                              "vs_lightgcn": wall / wall_g, "edge_softmax_us_per_layer": sm_us,
@@ -380,7 +380,7 @@ def run_cfg3(args, ctx):
                                             reps=50, settle=5)
         # second workload: every pair its own user (4096 distinct rated sets): nothing to share, the per-pair kernel
         distinct = None
-        if not per_pair and os.environ.get("NCF_CFG3_NO_DISTINCT") != "1":
+        if not per_pair and not getattr(args, "no_variants", False) and os.environ.get("NCF_CFG3_NO_DISTINCT") != "1":
 
             model_d, catalogue_d, batches_d = cfg3_workload(device, users=B, n_batches=2)
             model_d.precompute_catalog(catalogue_d)

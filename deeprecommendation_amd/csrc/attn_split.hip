@@ -415,7 +415,7 @@ extern "C" int ncf_attn_forward_split(int mode, const float* pc, int64_t ldpc, c
                                       float b1, const int64_t* rowptr, const int32_t* col, const float* val, int64_t R, int64_t I,
                                       const int64_t* grp_ptr, const int64_t* pair_ids, const int64_t* wg_ptr, const int32_t* wg_row,
                                       int64_t B, int pairs_per_wg, const float* feat, int64_t ldfeat, int Fdim, const float* out_bias,
-                                      float* out, int64_t ldout, int nsplit, void* workspace, size_t workspace_bytes,
+                                      float* out, int64_t ldout, int nsplit, int merge, void* workspace, size_t workspace_bytes,
                                       ncf_stream_t stream) {
     if (!ncf_attn_split_supported(mode, A, Fdim, pairs_per_wg))
         return fail(NCF_EUNSUPPORTED, "ncf_attn_forward_split: needs MLP / cosine mode, A %% 32 == 0 and <= 256, Fdim 64 or 128 (A = %d, Fdim = %d)", A, Fdim);
@@ -472,7 +472,7 @@ extern "C" int ncf_attn_forward_split(int mode, const float* pc, int64_t ldpc, c
 #undef LAUNCH_SP_J
 #undef LAUNCH_SP
     int rc = check_launch("ncf_attn_forward_split");
-    if (rc != NCF_OK || nsplit == 1) return rc;
+    if (rc != NCF_OK || nsplit == 1 || !merge) return rc;   // merge == 0: the partials stay in the workspace (ncf_attn_tail merges them)
     const int64_t n = B * (Fdim / 4);
     hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace, Fdim + kPartHead, nsplit, B,
                        Fdim, out_bias, out, ldout);

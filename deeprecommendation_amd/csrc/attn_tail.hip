@@ -1,0 +1,137 @@
+// K3 tail — the end of an AttentionNCF forward in ONE launch (models/attention_ncf.py:208-222), fp32, gfx950:
+//   user_emb = merge of the entry-split attention's softmax partials (attn_split.hip)  [+ UserEmbeddings bias]      (:208-216)
+//   out      = MLP(cat(candidate_emb, user_emb))      Linear, ReLU, Linear, ReLU, Linear -> 1                        (:219-222, util.py:5-18)
+// Round 3's first form ran attn_combine_kernel (3 us + a launch boundary) and then the small fused scoring kernel, whose 32-pair
+// tiles give a 4096-pair batch 128 workgroups of one wave per SIMD: 12.4 us for 0.5 GFLOP.  Here a workgroup takes 16 pairs (256
+// workgroups for 4096 pairs: every CU), merges their partials straight into the concatenated input tile in LDS, and runs the three
+// layers on v_mfma_f32_16x16x4_f32 (exact fp32 fmaf chains) with 8 waves sharing the tile: layer ℓ's 16-neuron column tiles are
+// dealt over the waves, activations live in LDS ([16][width + 4]: bank spread), weights stream from L2 in plain row-major layout
+// (lane (i, g) reads W[16 ct + i][16 kk + 4 g ..+3]: the k pairing of a 16-wide block is (4 g + j) for MFMA step j, the same for the
+// activation operand, so only the summation order inside a block is permuted).  Weight fragments run two k-blocks ahead in registers.
+// No bit-identity with mlp_fused.hip's k order is claimed (another summation order; 1e-5 of the oracle holds).
+#include "ncf_common.h"
+#include "attn_util.h"
+
+namespace ncf {
+
+struct TailArgs {
+    const float* cand; int64_t ldcand;          // (B, EA) candidate embeddings
+    const float* part; int nsplit, ldpart;      // (B, nsplit, UE + 4) softmax partials  (nsplit >= 1)
+    const float* user; int64_t lduser;          // OR (B, UE) finished user embeddings (part == nullptr)
+    const float* ubias;                         // UserEmbeddings bias added to the merged rows (may be null)
+    const float* W1; const float* b1; const float* W2; const float* b2; const float* w3; float b3;
+    float* out;
+    int64_t B;
+};
+
+constexpr int kTailHead = 4;   // floats in front of a partial's O (attn_split.hip kPartHead)
+
+template <int EA, int UE, int N1, int N2>
+__global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs a) {
+    constexpr int K0 = EA + UE, TM = 16, NWV = 8;
+    constexpr int XS = K0 + 4, H1S = N1 + 4, H2S = N2 + 4;
+    __shared__ __attribute__((aligned(16))) float xs[TM * XS];
+    __shared__ __attribute__((aligned(16))) float h1[TM * H1S];
+    __shared__ __attribute__((aligned(16))) float h2[TM * H2S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * TM;
+
+    // ---- the input tile: cat(candidate_emb, user_emb) (:219, candidate first) ----
+    for (int o = tid; o < TM * (K0 / 4); o += 512) {
+        const int r = o / (K0 / 4), c = o - r * (K0 / 4);
+        const int64_t b = row0 + r < a.B ? row0 + r : a.B - 1;
+        f32x4 v;
+        if (c < EA / 4) {
+            v = *reinterpret_cast<const f32x4*>(a.cand + b * a.ldcand + 4 * c);
+        } else {
+            const int cu = c - EA / 4;
+            if (a.part) {   // out = sum_s O_s e^(m_s - M) / sum_s l_s e^(m_s - M) + bias, slices in index order (attn_combine_kernel's order)
+                const float* p0 = a.part + b * a.nsplit * (int64_t)a.ldpart;
+                float M = -INFINITY;
+                for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, p0[(int64_t)s * a.ldpart]);
+                float L = 0.f;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int s = 0; s < a.nsplit; ++s) {
+                    const float* ps = p0 + (int64_t)s * a.ldpart;
+                    const float ms = ps[0];
+                    const float w = (ms == -INFINITY) ? 0.f : exp_le0(ms - M);
+                    L += ps[1] * w;
+                    acc += *reinterpret_cast<const f32x4*>(ps + kTailHead + 4 * cu) * w;
+                }
+                const float inv = L > 0.f ? 1.0f / L : 0.f;
+                f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+                if (a.ubias) bias = *reinterpret_cast<const f32x4*>(a.ubias + 4 * cu);
+                v = acc * inv + bias;
+            } else {
+                v = *reinterpret_cast<const f32x4*>(a.user + b * a.lduser + 4 * cu);
+            }
+        }
+        *reinterpret_cast<f32x4*>(xs + r * XS + 4 * c) = v;
+    }
+    __syncthreads();
+
+    // one layer: OUT[pair][n] = act(bias[n] + sum_k IN[pair][k] W[n][k]) for this wave's column tiles ct = wave, wave + 8, ...
+    auto layer = [&](const float* in, int ins, int K, const float* __restrict__ W, const float* __restrict__ bias, int N, float* outp, int outs) {
+        const int KB = K / 16;
+        for (int ct = wave; ct < N / 16; ct += NWV) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* wrow = W + (int64_t)(16 * ct + i16) * K + 4 * g4;
+            const float* irow = in + i16 * ins + 4 * g4;
+            f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow);
+            f32x4 w1 = *reinterpret_cast<const f32x4*>(wrow + (KB > 1 ? 16 : 0));
+            for (int kk = 0; kk < KB; ++kk) {                  // weight fragments two k-blocks ahead (L2 latency under the MFMAs)
+                const f32x4 wv = w0;
+                w0 = w1;
+                w1 = *reinterpret_cast<const f32x4*>(wrow + 16 * (kk + 2 < KB ? kk + 2 : KB - 1));
+                const f32x4 av = *reinterpret_cast<const f32x4*>(irow + 16 * kk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc, 0, 0, 0);
+            }
+            const float bv = bias[16 * ct + i16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) outp[(4 * g4 + i) * outs + 16 * ct + i16] = fmaxf(acc[i] + bv, 0.f);   // ReLU (util.py:12-14)
+        }
+    };
+    layer(xs, XS, K0, a.W1, a.b1, N1, h1, H1S);
+    __syncthreads();
+    layer(h1, H1S, N1, a.W2, a.b2, N2, h2, H2S);
+    __syncthreads();
+    // last layer (N2 -> 1, no activation): wave 0, lane (pair, quarter): a quarter of the dot each, quarters added in order
+    if (wave == 0) {
+        const float* hrow = h2 + i16 * H2S;
+        float s = 0.f;
+        for (int k = g4 * (N2 / 4); k < (g4 + 1) * (N2 / 4); ++k) s = fmaf(hrow[k], a.w3[k], s);
+        const float s1 = __shfl(s, i16 + 16), s2 = __shfl(s, i16 + 32), s3 = __shfl(s, i16 + 48);
+        if (g4 == 0 && row0 + i16 < a.B) a.out[row0 + i16] = ((s + s1) + (s2 + s3)) + a.b3;
+    }
+}
+
+}  // namespace ncf
+
+using namespace ncf;
+
+extern "C" int ncf_attn_tail_supported(int EA, int UE, int N1, int N2) {
+    return ((EA == 64 && UE == 64) || (EA == 128 && UE == 128)) && N1 == 256 && N2 == 128;
+}
+
+extern "C" int ncf_attn_tail(const float* cand, int64_t ldcand, int EA, const float* part, int nsplit, const float* user, int64_t lduser,
+                             int UE, const float* ubias, const float* W1, const float* b1, int N1, const float* W2, const float* b2, int N2,
+                             const float* w3, float b3, float* out, int64_t B, ncf_stream_t stream) {
+    if (!ncf_attn_tail_supported(EA, UE, N1, N2))
+        return fail(NCF_EUNSUPPORTED, "ncf_attn_tail: takes item_emb = user_emb in {64, 128} and MLP [256, 128] (EA = %d, UE = %d, MLP [%d, %d])", EA, UE, N1, N2);
+    if (B < 0 || ldcand < EA || (!part && lduser < UE) || (part && (nsplit < 1 || nsplit > 64))) return fail(NCF_EINVAL, "ncf_attn_tail: bad sizes");
+    if (B == 0) return NCF_OK;
+    if (!cand || (!part && !user) || !W1 || !b1 || !W2 || !b2 || !w3 || !out) return fail(NCF_EINVAL, "ncf_attn_tail: null pointer");
+    if (ldcand % 4 || (!part && lduser % 4) || !aligned16(cand) || (part && !aligned16(part)) || (user && !aligned16(user)) || !aligned16(W1) ||
+        !aligned16(W2) || (ubias && !aligned16(ubias)))
+        return fail(NCF_EINVAL, "ncf_attn_tail: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+    TailArgs a{};
+    a.cand = cand; a.ldcand = ldcand; a.part = part; a.nsplit = nsplit; a.ldpart = UE + kTailHead; a.user = user; a.lduser = lduser;
+    a.ubias = ubias; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out; a.B = B;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((B + 15) / 16);
+    if (EA == 64) hipLaunchKernelGGL((attn_tail_kernel<64, 64, 256, 128>), dim3(blocks), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((attn_tail_kernel<128, 128, 256, 128>), dim3(blocks), dim3(512), 0, s, a);
+    return check_launch("ncf_attn_tail");
+}

@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["abi.hip", "gather.hip", "mlp_fused.hip", "linear.hip", "spmm.hip", "attn.hip", "attn_split.hip", "attn_cand.hip", "mlp_bf16.hip", "mlp_bf16_ws8.hip", "backward.hip", "exchange.hip", "dense_csr.hip", "probe.hip"]
+SOURCES = ["abi.hip", "gather.hip", "mlp_fused.hip", "linear.hip", "spmm.hip", "attn.hip", "attn_split.hip", "attn_cand.hip", "attn_tail.hip", "mlp_bf16.hip", "mlp_bf16_ws8.hip", "backward.hip", "exchange.hip", "dense_csr.hip", "probe.hip"]
 LIB = os.path.join(PKG, "libncf_hip.so")
 ARCH = "gfx950"
 # per-file flags.  mlp_bf16.hip: MFMA accumulators in VGPRs instead of AGPRs (the ReLU / bf16 conversion of the hidden

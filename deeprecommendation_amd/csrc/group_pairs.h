@@ -11,12 +11,12 @@ namespace ncf {
 // otherwise serialises 65 536 atomics on a single counter in each pass (~0.65 ms each, measured 2.0 ms per request).
 // Returns the value the lane's own atomicAdd(&counter[r], 1) would have returned in SOME valid order; inactive lanes
 // (valid == false) take no part.
-__device__ __forceinline__ int wave_aggregated_inc(int* __restrict__ counter, int64_t r, bool valid) {
+__device__ __forceinline__ int wave_aggregated_inc(int* __restrict__ counter, int64_t r, bool valid, bool aggregate = true) {
     int result = 0;
     bool pending = valid;
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {               // two rounds take the one or two hot rows of a wave ...
+    for (int round = 0; round < 2 && aggregate; ++round) {  // two rounds take the one or two hot rows of a wave ...
         const unsigned long long todo = __ballot(pending);
         if (todo == 0) break;
         const int leader = __ffsll((long long)todo) - 1;
@@ -52,6 +52,9 @@ __device__ __forceinline__ void group_small_body(const int64_t* __restrict__ pai
                                                  int64_t* __restrict__ grp_ptr, int64_t* __restrict__ wg_ptr,
                                                  int64_t* __restrict__ pair_ids, int32_t* __restrict__ wg_row, int* lds) {
     constexpr int NWV = NT / 64;
+    // pairs spread over many rows (an evaluation batch in random user order) rarely meet in a wave: the aggregation rounds would be
+    // ~80 instructions of pure overhead per 64 pairs; they pay when a few rows hold most pairs (one user x a whole catalogue)
+    const bool aggregate = R <= 16;                        // >= 4 lanes of a wave per row on average
     if (B <= 0) {                                           // nothing to list: empty groups
         for (int64_t i = threadIdx.x; i <= R; i += NT) { grp_ptr[i] = 0; wg_ptr[i] = 0; }
         return;
@@ -87,7 +90,7 @@ __device__ __forceinline__ void group_small_body(const int64_t* __restrict__ pai
             const int64_t r = b < B ? rr[u] : -1;
             const bool ok = b < B && r >= 0 && r < R;
             if (b < B && !ok) *bad = 1;
-            (void)wave_aggregated_inc(counts, r, ok);
+            (void)wave_aggregated_inc(counts, r, ok, aggregate);
         }
     }
     __syncthreads();
@@ -151,7 +154,7 @@ __device__ __forceinline__ void group_small_body(const int64_t* __restrict__ pai
             if (base + (int64_t)u * NT >= B) break;
             const int64_t r = b < B ? rr[u] : -1;
             const bool ok = b < B && r >= 0 && r < R;
-            const int slot = wave_aggregated_inc(cursor, r, ok);
+            const int slot = wave_aggregated_inc(cursor, r, ok, aggregate);
             if (ok) pair_ids[slot] = b;
         }
     }

@@ -202,6 +202,77 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(const int64_t* __rest
     }
 }
 
+
+// The same softmax over the SEGMENTS of the SpMM (rows longer than 512 edges are split; a hub item of BASELINE config 4 has 4 M
+// in-edges: one wave walking them three times is ~0.2 s, the whole 100 M-edge graph otherwise ~1 ms).  Three passes, every one
+// parallel over segments or rows, no atomics, fixed order (bitwise repeatable):
+//   1. per segment (one wave):  m_seg = max s[col[e]],  l_seg = sum exp(s[col[e]] - m_seg)
+//   2. per row (one wave over the row's segments [seg_first[r], seg_first[r+1])):  M = max m_seg,  L = sum l_seg exp(m_seg - M)
+//   3. per segment:  out[e] = (attr ? attr[e] : 1) * exp(s[col[e]] - M_row) / (L_row + 1e-16)
+__global__ __launch_bounds__(256) void edge_softmax_seg_stats_kernel(const int64_t* __restrict__ segptr, int64_t n_seg, const int32_t* __restrict__ col,
+                                                                     const float* __restrict__ s, int64_t Ns, float* __restrict__ segm,
+                                                                     float* __restrict__ segl) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t g = wave0; g < n_seg; g += nwaves) {
+        const int64_t beg = segptr[g], end = segptr[g + 1];
+        float mx = -INFINITY;
+        for (int64_t e = beg + lane; e < end; e += 64) {
+            const int64_t c = col[e];
+            if (c >= 0 && c < Ns) mx = fmaxf(mx, s[c]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float sm = 0.f;
+        for (int64_t e = beg + lane; e < end; e += 64) {
+            const int64_t c = col[e];
+            if (c >= 0 && c < Ns) sm += expf(s[c] - mx);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sm += __shfl_xor(sm, off);
+        if (lane == 0) { segm[g] = mx; segl[g] = sm; }
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_softmax_row_stats_kernel(const int64_t* __restrict__ seg_first, int64_t n_rows, const float* __restrict__ segm,
+                                                                     const float* __restrict__ segl, float* __restrict__ rowm, float* __restrict__ rowden) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave0; r < n_rows; r += nwaves) {
+        const int64_t beg = seg_first[r], end = seg_first[r + 1];
+        float mx = -INFINITY;
+        for (int64_t g = beg + lane; g < end; g += 64) mx = fmaxf(mx, segm[g]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float sm = 0.f;
+        for (int64_t g = beg + lane; g < end; g += 64) {
+            const float m = segm[g];
+            if (m != -INFINITY) sm += segl[g] * expf(m - mx);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sm += __shfl_xor(sm, off);
+        if (lane == 0) { rowm[r] = mx; rowden[r] = sm + 1e-16f; }
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_softmax_seg_apply_kernel(const int64_t* __restrict__ segptr, const int32_t* __restrict__ row_of, int64_t n_seg,
+                                                                     const int32_t* __restrict__ col, const float* __restrict__ attr,
+                                                                     const float* __restrict__ s, int64_t Ns, const float* __restrict__ rowm,
+                                                                     const float* __restrict__ rowden, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t g = wave0; g < n_seg; g += nwaves) {
+        const int64_t beg = segptr[g], end = segptr[g + 1];
+        const int64_t r = row_of[g];
+        const float mx = rowm[r], den = rowden[r];
+        for (int64_t e = beg + lane; e < end; e += 64) {
+            const int64_t c = col[e];
+            const float a = (c >= 0 && c < Ns) ? expf(s[c] - mx) / den : 0.f;
+            out[e] = attr ? attr[e] * a : a;
+        }
+    }
+}
+
 template <int LPR>
 static void launch_spmm(const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int32_t* col, const float* coef,
                         const float* z, int64_t Nz, int64_t ldz, int chunks, float* y, int64_t ldy, float* sum, int64_t ldsum,
@@ -306,4 +377,29 @@ extern "C" int ncf_edge_softmax_csr(const int64_t* rowptr, const int32_t* col, c
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(edge_softmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, attr, s, n_rows, Ns, out);
     return check_launch("ncf_edge_softmax_csr");
+}
+
+extern "C" size_t ncf_edge_softmax_segmented_workspace_bytes(int64_t n_seg, int64_t n_rows) {
+    return (size_t)(2 * (n_seg > 0 ? n_seg : 0) + 2 * (n_rows > 0 ? n_rows : 0)) * sizeof(float);
+}
+
+extern "C" int ncf_edge_softmax_segmented(const int64_t* segptr, const int32_t* row_of, int64_t n_seg, const int64_t* seg_first, int64_t n_rows,
+                                          const int32_t* col, const float* attr, const float* s, int64_t Ns, float* out, void* workspace,
+                                          size_t workspace_bytes, ncf_stream_t stream) {
+    if (n_rows < 0 || n_seg < 0 || Ns < 0) return fail(NCF_EINVAL, "ncf_edge_softmax_segmented: bad sizes");
+    if (n_rows == 0 || n_seg == 0) return NCF_OK;
+    if (!segptr || !row_of || !seg_first || !s || !workspace) return fail(NCF_EINVAL, "ncf_edge_softmax_segmented: null pointer");
+    if (workspace_bytes < ncf_edge_softmax_segmented_workspace_bytes(n_seg, n_rows)) return fail(NCF_EWORKSPACE, "ncf_edge_softmax_segmented: workspace too small");
+    float* segm = (float*)workspace;
+    float* segl = segm + n_seg;
+    float* rowm = segl + n_seg;
+    float* rowden = rowm + n_rows;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t bs = (n_seg + 3) / 4, br = (n_rows + 3) / 4;
+    if (bs > 256 * 64) bs = 256 * 64;
+    if (br > 256 * 64) br = 256 * 64;
+    hipLaunchKernelGGL(edge_softmax_seg_stats_kernel, dim3((unsigned)bs), dim3(256), 0, st, segptr, n_seg, col, s, Ns, segm, segl);
+    hipLaunchKernelGGL(edge_softmax_row_stats_kernel, dim3((unsigned)br), dim3(256), 0, st, seg_first, n_rows, segm, segl, rowm, rowden);
+    hipLaunchKernelGGL(edge_softmax_seg_apply_kernel, dim3((unsigned)bs), dim3(256), 0, st, segptr, row_of, n_seg, col, attr, s, Ns, rowm, rowden, out);
+    return check_launch("ncf_edge_softmax_segmented");
 }

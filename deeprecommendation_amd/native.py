@@ -81,8 +81,13 @@ SIGNATURES = {
     "ncf_attn_split_workspace_bytes": (_c_size, [_c_i64, _c_int, _c_int]),
     "ncf_attn_forward_split": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
                                         _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_int, _c_p, _c_p,
-                                        _c_i64, _c_int, _c_p, _c_size, _c_p]),
+                                        _c_i64, _c_int, _c_int, _c_p, _c_size, _c_p]),
+    "ncf_attn_tail_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
+    "ncf_attn_tail": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_int, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int,
+                               _c_p, ctypes.c_float, _c_p, _c_i64, _c_p]),
     "ncf_edge_softmax_csr": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "ncf_edge_softmax_segmented_workspace_bytes": (_c_size, [_c_i64, _c_i64]),
+    "ncf_edge_softmax_segmented": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_size, _c_p]),
     "ncf_score_folded_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "ncf_score_folded": (_c_int, [_c_int, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p,
                                   _c_p, _c_p, _c_p]),
@@ -814,6 +819,37 @@ def attn_candidates(x: torch.Tensor, Wi: torch.Tensor, bi: Optional[torch.Tensor
     return emb, pc, grp
 
 
+class AttnPartials:
+    """The entry-split attention's un-merged softmax partials: (B, nsplit, Fdim + 4) floats in ``ws`` — what attn_tail() merges."""
+
+    def __init__(self, ws, nsplit, Fdim, B):
+        self.ws, self.nsplit, self.Fdim, self.B = ws, int(nsplit), int(Fdim), int(B)
+
+
+def attn_tail_supported(EA: int, UE: int, N1: int, N2: int) -> bool:
+    return bool(load_library().ncf_attn_tail_supported(int(EA), int(UE), int(N1), int(N2)))
+
+
+def attn_tail(cand_emb: torch.Tensor, user, ubias: Optional[torch.Tensor], W1, b1, W2, b2, w3, b3: float) -> torch.Tensor:
+    """ncf_attn_tail: merge of the attention partials (``user`` an AttnPartials; ``ubias`` = UserEmbeddings' bias) or finished user
+    embeddings (``user`` a (B, UE) tensor, ``ubias`` None), cat(candidate_emb, user_emb), MLP -> (B, 1)."""
+    lib = load_library()
+    _dev(cand_emb, "cand_emb")
+    B, EA, ldc = _rows2d(cand_emb, "cand_emb")
+    N1, N2 = int(W1.shape[0]), int(W2.shape[0])
+    out = torch.empty((B, 1), dtype=torch.float32, device=cand_emb.device)
+    if isinstance(user, AttnPartials):
+        part, ns, uptr, ldu, UE = user.ws, user.nsplit, None, 0, user.Fdim
+    else:
+        _, UE, ldu = _rows2d(user, "user_emb")
+        part, ns, uptr = None, 1, user
+    if W1.shape[1] != EA + UE or W2.shape[1] != N1 or w3.numel() != N2 or not (W1.is_contiguous() and W2.is_contiguous() and w3.is_contiguous()):
+        raise ValueError("attn_tail: MLP weights do not match cat(candidate_emb, user_emb)")
+    _check(lib.ncf_attn_tail(_ptr(cand_emb), ldc, EA, _ptr(part), ns, _ptr(uptr), ldu, UE, _ptr(ubias), _ptr(W1), _ptr(b1), N1, _ptr(W2), _ptr(b2), N2,
+                             _ptr(w3), float(b3), _ptr(out), B, _stream(cand_emb)))
+    return out
+
+
 def attn_split_supported(mode: int, A: int, Fdim: int, pairs_per_wg: int) -> bool:
     return bool(load_library().ncf_attn_split_supported(int(mode), int(A), int(Fdim), int(pairs_per_wg)))
 
@@ -836,7 +872,8 @@ def num_cus() -> int:
 def attn_forward_grouped(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Optional[torch.Tensor], b1: float,
                          rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, pair_row: torch.Tensor,
                          feat: torch.Tensor, out_bias: Optional[torch.Tensor] = None, pairs_per_wg: Optional[int] = None,
-                         grouping=None, return_weights: bool = False, nsplit: Optional[int] = None, nnz_hint: Optional[int] = None):
+                         grouping=None, return_weights: bool = False, nsplit: Optional[int] = None, nnz_hint: Optional[int] = None,
+                         leave_partials: bool = False):
     """LDS-tiled attention for pairs that share rated sets: CSR row ``pair_row[b]`` is pair b's set.  Returns out_feat
     (B, Fdim), or (out_feat, weights) with ``return_weights``: the attention weights in the layout of the expanded
     per-pair CSR (``SparseRatings.expanded()``).  ``grouping`` = (group_pairs(pair_row, R, ppw), ppw) computed earlier
@@ -872,7 +909,9 @@ def attn_forward_grouped(mode: int, pc: torch.Tensor, pr: torch.Tensor, w1: Opti
         _check(lib.ncf_attn_forward_split(mode, _ptr(pc), ldpc, _ptr(pr), ldpr, A, _ptr(w1), float(b1), _ptr(rowptr), _ptr(col),
                                           _ptr(val), R, I, _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr), _ptr(wg_row), B,
                                           int(pairs_per_wg), _ptr(feat), ldf, Fdim, _ptr(out_bias), _ptr(out), out.stride(0),
-                                          ns, _ptr(ws), nbytes, _stream(pc)))
+                                          ns, 0 if (leave_partials and ns > 1) else 1, _ptr(ws), nbytes, _stream(pc)))
+        if leave_partials and ns > 1:
+            return AttnPartials(ws, ns, Fdim, B)
         return out
     wts = wts_off = None
     if return_weights:
@@ -921,11 +960,21 @@ def score_folded(PA: torch.Tensor, idxA, PB: torch.Tensor, idxB, packed_tail: Pa
 
 
 def edge_softmax_csr(rowptr: torch.Tensor, col: torch.Tensor, attr: Optional[torch.Tensor], s: torch.Tensor,
-                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, segments=None) -> torch.Tensor:
+    """Per-destination softmax of the source scores times the edge weight (LightGAT).  ``segments`` = (segptr, row_of, seg_first) of
+    the SpMM's split rows: the segmented form (parallel over segments: hub rows do not serialise on one wave)."""
     lib = load_library()
     _dev(s, "s")
     if out is None:
         out = torch.empty(max(col.numel(), 1), dtype=torch.float32, device=s.device)[:col.numel()]
+    if segments is not None and segments[1] is not None:
+        segptr, row_of, seg_first = segments
+        n_seg, n_rows = segptr.numel() - 1, rowptr.numel() - 1
+        nbytes = lib.ncf_edge_softmax_segmented_workspace_bytes(n_seg, n_rows)
+        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=s.device)
+        _check(lib.ncf_edge_softmax_segmented(_ptr(segptr), _ptr(row_of), n_seg, _ptr(seg_first), n_rows, _ptr(col), _ptr(attr), _ptr(s), s.numel(),
+                                              _ptr(out), _ptr(ws), nbytes, _stream(s)))
+        return out
     _check(lib.ncf_edge_softmax_csr(_ptr(rowptr), _ptr(col), _ptr(attr), _ptr(s), rowptr.numel() - 1, s.numel(), _ptr(out), _stream(s)))
     return out
 

@@ -207,6 +207,22 @@ class AttentionNCF(_ScoringMixin, NCF):
             cache["att_split"] = ((w[:, :IE] * f).contiguous(), (w[:, IE:] * f).contiguous(), (l0.bias.detach() * f).contiguous())
         return cache["att_split"]
 
+    def _tail_mlp(self, cache):
+        """(W1, b1, W2, b2, w3, b3) for ncf_attn_tail when the MLP has its shape (two hidden layers [256, 128] over item_emb = user_emb
+        in {64, 128}: the class default and the shipped checkpoints), else None.  Cached per weight version (b3 is read once)."""
+        if "tail_mlp" not in cache:
+            from ..util import mlp_linears
+            lins = mlp_linears(self.MLP)
+            IE, UE = self.ItemEmbeddings[0].out_features, self.UserEmbeddings[0].out_features
+            ok = (len(lins) == 3 and lins[2].out_features == 1 and not self.fold_first_layer
+                  and native.attn_tail_supported(IE, UE, lins[0].out_features, lins[1].out_features))
+            cache["tail_mlp"] = None
+            if ok:
+                cache["tail_mlp"] = (lins[0].weight.detach().contiguous(), lins[0].bias.detach().contiguous(),
+                                     lins[1].weight.detach().contiguous(), lins[1].bias.detach().contiguous(),
+                                     lins[2].weight.detach().reshape(-1).contiguous(), float(lins[2].bias.detach().item()))
+        return cache["tail_mlp"]
+
     def precompute_catalog(self, rated_items: torch.Tensor, cache=None):
         """Everything that depends only on the rated-item list: its embeddings, the rated half of the attention
         projection and the UserEmbeddings projection of the raw features.  Cached for the last list seen (serving
@@ -311,10 +327,15 @@ class AttentionNCF(_ScoringMixin, NCF):
                 mode, w1, b1 = native.ATT_LINEAR, None, 0.0
         if grouped:
             # several pairs per rated set: stage each set once per workgroup in LDS (K3 grouped form)
+            tail = None if return_attention_weights else self._tail_mlp(cache)
             res = native.attn_forward_grouped(mode, pc, pr, w1, b1, ratings.rowptr, ratings.col, ratings.val,
                                               ratings.pair_row, proj, out_bias=lu.bias.detach(),
                                               return_weights=return_attention_weights, grouping=grouping,
-                                              nnz_hint=getattr(ratings, "nnz_hint", None))
+                                              nnz_hint=getattr(ratings, "nnz_hint", None), leave_partials=tail is not None)
+            if tail is not None:
+                # ONE launch: merge of the attention's partials (+ UserEmbeddings' bias), cat(candidate_emb, user_emb), MLP (:208-222)
+                parts = isinstance(res, native.AttnPartials)
+                return native.attn_tail(cand_emb, res, lu.bias.detach() if parts else None, *tail)
             if return_attention_weights:
                 out = self._score(cand_emb, None, res[0], None, cache=cache)
                 return out, ratings.expanded().to_dense(res[1])

@@ -140,6 +140,15 @@ class PreparedGraph:
         self._edges = (u2i, i2u)          # references only: the training step derives its per-edge keys on first use
         native.check_oob(dev)
 
+    def softmax_segments(self):
+        """(segptr, row_of, seg_first) for the segmented edge softmax (LightGAT): seg_first[r] = first segment of destination r.  None
+        when no row was split (segments == rows)."""
+        if self.row_of is None:
+            return None
+        if getattr(self, "_seg_first", None) is None:
+            self._seg_first = torch.searchsorted(self.row_of.to(torch.int64), torch.arange(self.N + 1, device=self.row_of.device)).contiguous()
+        return self.segptr, self.row_of, self._seg_first
+
     def transposed(self):
         """(CSR by SOURCE, edge ids): entry k of the transpose is entry eid[k] of the CSR by destination — the backward of the
         aggregation, dz[src] += coef_e * dy[dst], is the same segmented SpMM on it.  Built on first use (training only)."""
@@ -289,7 +298,7 @@ class LightGATConv(_ConvBase):
                 native.linear(x[:I], self.item2user_AttNet[0].weight.detach()[:, :D].contiguous(), None, out=s[:I])
             if x.shape[0] > I:
                 native.linear(x[I:], self.user2item_AttNet[0].weight.detach()[:, :D].contiguous(), None, out=s[I:])
-        coef = native.edge_softmax_csr(prep.rowptr, prep.col, prep.attr, s.view(-1))
+        coef = native.edge_softmax_csr(prep.rowptr, prep.col, prep.attr, s.view(-1), segments=prep.softmax_segments())
         return prep.csr.spmm(self.hoisted(x, prep), acc_sum=acc_sum, coef=coef)
 
     def forward(self, x, user2item_edge_index, item2user_edge_index, user2item_edge_attr=None, item2user_edge_attr=None):

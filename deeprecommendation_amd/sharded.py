@@ -660,7 +660,11 @@ class PartitionedLightGCN:
 
     def _edge_softmax(self, s):
         if self.ops is None:
-            return native.edge_softmax_csr(self.rowptr, self.col, self.attr, s)
+            if getattr(self, "_softmax_seg", None) is None:       # the local CSR's segments (hub rows are split: no wave walks millions of edges)
+                segptr, row_of, _ = self.csr.levels[0]
+                self._softmax_seg = False if row_of is None else (
+                    segptr, row_of, torch.searchsorted(row_of.to(torch.int64), torch.arange(self.rowptr.numel(), device=row_of.device)).contiguous())
+            return native.edge_softmax_csr(self.rowptr, self.col, self.attr, s, segments=self._softmax_seg or None)
         return self.ops.edge_softmax(self.rowptr, self.col, self.attr, s)
 
     def _propagate_gat(self, x0):

@@ -246,6 +246,14 @@ int ncf_edge_coef(const int64_t* dev_src, const int64_t* dev_dst, const float* d
  * group and cancels in the softmax).  The result is the per-edge coefficient for ncf_spmm_csr. */
 int ncf_edge_softmax_csr(const int64_t* dev_rowptr, const int32_t* dev_col, const float* dev_attr, const float* dev_s,
                          int64_t n_rows, int64_t Ns, float* dev_out, ncf_stream_t stream);
+/* The same function over the SEGMENTS of the SpMM's split rows (dev_segptr / dev_row_of of ncf_spmm_csr, dev_seg_first[r] = first
+ * segment of row r, n_rows + 1 entries): three passes parallel over segments / rows instead of one wave per destination — a hub
+ * destination with millions of in-edges no longer serialises.  Fixed order, no atomics; equal to ncf_edge_softmax_csr up to the
+ * fp32 summation order.  workspace: ncf_edge_softmax_segmented_workspace_bytes(n_seg, n_rows). */
+size_t ncf_edge_softmax_segmented_workspace_bytes(int64_t n_seg, int64_t n_rows);
+int ncf_edge_softmax_segmented(const int64_t* dev_segptr, const int32_t* dev_row_of, int64_t n_seg, const int64_t* dev_seg_first,
+                               int64_t n_rows, const int32_t* dev_col, const float* dev_attr, const float* dev_s, int64_t n_src,
+                               float* dev_out, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
 
 /* out[n, :] = in[n, :] / divisor  (the division of torch.mean over the L+1 stacked layers, gnn_ncf.py:351). */
 int ncf_scale_rows(const float* dev_in, int64_t ldin, int64_t N, int D, float divisor,
@@ -364,7 +372,7 @@ int ncf_group_pairs_rows(const int64_t* dev_pair_row, int64_t B, int64_t n_rows,
 /* Entry-split form of ncf_attn_forward_grouped (same operands and result; attention weights are not available here):
  * the rated set of a row is cut into `nsplit` slices of whole 64-entry tiles, one workgroup per (group of pairs, slice)
  * leaves a softmax partial (running maximum, sum, un-normalised aggregate) in dev_workspace and a second kernel of the same
- * call merges them in slice order (deterministic).  Replaces the same reference lines as ncf_attn_forward_grouped
+ * call merges them in slice order (deterministic; merge = 0 leaves them for ncf_attn_tail).  Replaces the same reference lines as ncf_attn_forward_grouped
  * (models/attention_ncf.py:154-216); it exists because a batch of a few thousand pairs is too few workgroups of too long
  * a chain for the one-workgroup-per-group form.  nsplit = 1 needs no workspace and launches one kernel.
  * Shapes: ncf_attn_split_supported() (A % 32 == 0, A <= 256, Fdim 64 or 128, MLP / cosine modes); else NCF_EUNSUPPORTED.
@@ -380,7 +388,20 @@ int ncf_attn_forward_split(int mode,
                            const int32_t* dev_wg_row, int64_t B, int pairs_per_wg,
                            const float* dev_feat, int64_t ldfeat, int Fdim, const float* dev_out_bias,
                            float* dev_out_feat, int64_t ldout,
-                           int nsplit, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
+                           int nsplit, int merge, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
+
+/* The end of AttentionNCF.forward in one launch (models/attention_ncf.py:208-222): merge of the entry-split attention's partials
+ * (ncf_attn_forward_split with merge = 0: dev_part = its workspace, (B, nsplit, UE + 4) floats — [m, l, -, -, O...]) into the user
+ * embeddings (+ dev_ubias = UserEmbeddings' bias), cat(candidate_emb, user_emb) (:219), then the MLP of util.py:5-18
+ * (EA + UE -> N1 -> N2 -> 1, ReLU between, none after the last).  dev_part == NULL: dev_user holds finished (B, UE) rows.
+ * Weights in the reference's own layout: W1 (N1, EA + UE), W2 (N2, N1) row-major, w3 (N2).  Replaces attn_combine + the fused
+ * scoring kernel for evaluation batches (16 pairs per workgroup instead of 32: twice the workgroups).
+ * Shapes: ncf_attn_tail_supported (EA = UE in {64, 128}, N1 = 256, N2 = 128); else NCF_EUNSUPPORTED (use ncf_score_fused). */
+int ncf_attn_tail_supported(int EA, int UE, int N1, int N2);
+int ncf_attn_tail(const float* dev_cand_emb, int64_t ldcand, int EA,
+                  const float* dev_part, int nsplit, const float* dev_user, int64_t lduser, int UE, const float* dev_ubias,
+                  const float* dev_W1, const float* dev_b1, int N1, const float* dev_W2, const float* dev_b2, int N2,
+                  const float* dev_w3, float b3, float* dev_out, int64_t B, ncf_stream_t stream);
 
 /* Dense user_matrix -> CSR with shared rows, on the stream (no size is read by the host).  The reference passes AttentionNCF.forward a
  * dense (B, I) user_matrix in which a user's row is repeated for each of their samples (datasets/dynamic_datasets.py:24-40,

@@ -595,3 +595,50 @@ def test_attention_forward_dense_matrix_reference_eval_shape(gpu):
     with torch.no_grad():
         out = m(cand.to(gpu), rated.to(gpu), um)
     assert_close(out[sub], ref)
+
+
+@pytest.mark.parametrize("E,B,nsplit", [(64, 4096, 4), (64, 333, 1), (128, 1000, 3), (64, 17, 8), (128, 16, 1)])
+def test_attention_tail_kernel(gpu, E, B, nsplit):
+    """ncf_attn_tail — merge of the entry-split attention's softmax partials (+ UserEmbeddings' bias), cat(candidate_emb, user_emb)
+    (attention_ncf.py:219), MLP (util.py:5-18) in one launch — against a float64 evaluation of the same formulas; also with
+    finished user embeddings instead of partials, a ragged last tile, empty slices (m = -inf) and a pair whose slices are ALL empty."""
+    from deeprecommendation_amd import native
+    g = torch.Generator(device=gpu).manual_seed(E + B + nsplit)
+    cand = torch.randn(B, E, device=gpu, generator=g)
+    N1, N2 = 256, 128
+    W1 = (torch.randn(N1, 2 * E, device=gpu, generator=g) / (2 * E) ** 0.5).contiguous()
+    W2 = (torch.randn(N2, N1, device=gpu, generator=g) / N1 ** 0.5).contiguous()
+    b1, b2 = torch.randn(N1, device=gpu, generator=g) * 0.1, torch.randn(N2, device=gpu, generator=g) * 0.1
+    w3, b3 = torch.randn(N2, device=gpu, generator=g) / N2 ** 0.5, 0.37
+    ubias = torch.randn(E, device=gpu, generator=g) * 0.1
+    assert native.attn_tail_supported(E, E, N1, N2)
+
+    def mlp64(x):
+        h = torch.relu(x @ W1.double().t() + b1.double())
+        h = torch.relu(h @ W2.double().t() + b2.double())
+        return h @ w3.double().view(-1, 1) + b3
+
+    # finished user embeddings
+    user = torch.randn(B, E, device=gpu, generator=g)
+    out = native.attn_tail(cand, user, None, W1, b1, W2, b2, w3, b3)
+    assert_close(out, mlp64(torch.cat((cand, user), 1).double()))
+    # partials
+    part = torch.zeros(B, nsplit, E + 4, device=gpu)
+    m = torch.randn(B, nsplit, device=gpu, generator=g) * 3
+    l = torch.rand(B, nsplit, device=gpu, generator=g) * 5 + 0.1
+    O_ = torch.randn(B, nsplit, E, device=gpu, generator=g) * 2
+    if nsplit > 1:
+        m[::5, 1] = -float("inf")                      # an empty slice
+        l[::5, 1] = 0.0
+        O_[::5, 1] = 0.0
+    m[3] = -float("inf"); l[3] = 0.0; O_[3] = 0.0      # a pair with no rated entry at all: bias alone (the nan_to_num case)
+    part[:, :, 0], part[:, :, 1], part[:, :, 4:] = m, l, O_
+    ws = part.view(torch.uint8).view(-1)
+    M = m.double().max(dim=1, keepdim=True).values
+    w = torch.where(torch.isinf(m), torch.zeros_like(m.double()), torch.exp(m.double() - M))
+    w = torch.nan_to_num(w, nan=0.0)
+    L = (l.double() * w).sum(1, keepdim=True)
+    ue = torch.where(L > 0, (O_.double() * w[:, :, None]).sum(1) / L.clamp_min(1e-300), torch.zeros(B, E, dtype=torch.float64, device=gpu)) + ubias.double()
+    out2 = native.attn_tail(cand, native.AttnPartials(ws, nsplit, E, B), ubias, W1, b1, W2, b2, w3, b3)
+    assert_close(out2, mlp64(torch.cat((cand.double(), ue), 1)))
+    assert torch.equal(out2, native.attn_tail(cand, native.AttnPartials(ws, nsplit, E, B), ubias, W1, b1, W2, b2, w3, b3))

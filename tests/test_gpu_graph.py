@@ -163,24 +163,30 @@ def test_full_size_lightgat_properties(gpu, full_graph):
     N = I + U
     assert prep.type_pure
     s = torch.randn(N, device=gpu, generator=g) * 2.0
-    alpha = native.edge_softmax_csr(prep.rowptr, prep.col, None, s)
+    seg = prep.softmax_segments()
+    assert seg is not None                                   # hub rows are split: the segmented softmax is the one LightGAT runs
+    alpha = native.edge_softmax_csr(prep.rowptr, prep.col, None, s, segments=seg)
     assert alpha.numel() == prep.col.numel() and float(alpha.min()) >= 0.0
+    slow = native.edge_softmax_csr(prep.rowptr, prep.col, None, s)       # one wave per destination (the small-graph form): same function
+    assert float((slow - alpha).abs().max()) <= 1e-5 * float(alpha.max())
+    del slow
     counts = prep.rowptr[1:] - prep.rowptr[:-1]
-    sums = torch.zeros(N, dtype=torch.float64, device=gpu)
-    step = 10_000_000
-    row_of_edge = torch.repeat_interleave(torch.arange(N, device=gpu), counts)
-    for a in range(0, alpha.numel(), step):
-        sums.index_add_(0, row_of_edge[a:a + step], alpha[a:a + step].double())
+    # per-destination sums from a float64 prefix sum (no atomics: a hub item has millions of in-edges on ONE address)
+    cs = torch.zeros(alpha.numel() + 1, dtype=torch.float64, device=gpu)
+    torch.cumsum(alpha.double(), 0, out=cs[1:])
+    sums = cs[prep.rowptr[1:]] - cs[prep.rowptr[:-1]]
+    del cs
     nonempty = counts > 0
     err = float((sums[nonempty] - 1.0).abs().max())
     assert err <= 2e-5, f"attention weights of a destination do not sum to 1: {err:.3e}"      # hub rows add 4 M fp32 terms
-    assert float(sums[~nonempty].abs().max()) == 0.0 if bool((~nonempty).any()) else True
-    del row_of_edge, sums
-    assert torch.equal(alpha, native.edge_softmax_csr(prep.rowptr, prep.col, None, s))            # run to run, bit for bit
-    shifted = native.edge_softmax_csr(prep.rowptr, prep.col, None, s + 3.0)
+    if bool((~nonempty).any()):
+        assert float(sums[~nonempty].abs().max()) == 0.0
+    del sums
+    assert torch.equal(alpha, native.edge_softmax_csr(prep.rowptr, prep.col, None, s, segments=seg))   # run to run, bit for bit
+    shifted = native.edge_softmax_csr(prep.rowptr, prep.col, None, s + 3.0, segments=seg)
     assert float((shifted - alpha).abs().max()) <= 1e-5 * float(alpha.max())
     del shifted
-    coef = native.edge_softmax_csr(prep.rowptr, prep.col, prep.attr, s)
+    coef = native.edge_softmax_csr(prep.rowptr, prep.col, prep.attr, s, segments=seg)
     ref = prep.attr * alpha
     assert float((coef - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
     del ref, alpha
@@ -297,3 +303,40 @@ def test_graph_readout_with_folded_first_layer(gpu):
     assert any(isinstance(k, tuple) and k[0] == "folded" and v is not None for k, v in m._native_cache.items())
     assert_close(plain, ref)
     assert_close(folded, ref)
+
+
+@pytest.mark.parametrize("weighted", [True, False])
+def test_segmented_edge_softmax_equals_row_form(gpu, weighted):
+    """ncf_edge_softmax_segmented (three passes over the SpMM's segments) == ncf_edge_softmax_csr (one wave per destination) on a graph
+    with hub rows split into many segments, empty rows and sources out of range; and == the PyG softmax definition in float64."""
+    from deeprecommendation_amd import native
+    g = torch.Generator().manual_seed(5)
+    N, E = 300, 40_000
+    dst = torch.cat([torch.zeros(9000, dtype=torch.int64), torch.full((3000,), 7, dtype=torch.int64), torch.randint(10, N - 5, (E - 12000,), generator=g)])
+    src = torch.randint(0, N, (E,), generator=g)
+    order = torch.argsort(dst, stable=True)
+    dst, src = dst[order], src[order]
+    counts = torch.bincount(dst, minlength=N)
+    rowptr = torch.zeros(N + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    attr = torch.randn(E, generator=g) if weighted else None
+    s = torch.randn(N, generator=g) * 3
+    col = src.to(torch.int32)
+    col[5] = -1
+    col[20000] = N + 3
+    csr = native.SegmentedCSR(rowptr.to(gpu), col.to(gpu), None, seg_len=512)
+    segptr, row_of, _ = csr.levels[0]
+    assert row_of is not None
+    seg_first = torch.searchsorted(row_of.to(torch.int64), torch.arange(N + 1, device=gpu))
+    a_seg = native.edge_softmax_csr(rowptr.to(gpu), col.to(gpu), None if attr is None else attr.to(gpu), s.to(gpu), segments=(segptr, row_of, seg_first))
+    a_row = native.edge_softmax_csr(rowptr.to(gpu), col.to(gpu), None if attr is None else attr.to(gpu), s.to(gpu))
+    assert float((a_seg - a_row).abs().max()) <= 1e-6 * float(a_row.abs().max())
+    okc = (col >= 0) & (col < N)
+    sc = torch.where(okc, s[col.long().clamp(0, N - 1)].double(), torch.full((E,), -float("inf"), dtype=torch.float64))
+    mx = torch.full((N,), -float("inf"), dtype=torch.float64).scatter_reduce(0, dst, sc, reduce="amax", include_self=True)
+    ex = torch.where(okc, torch.exp(sc - mx[dst]), torch.zeros(E, dtype=torch.float64))
+    den = torch.zeros(N, dtype=torch.float64).index_add_(0, dst, ex)
+    ref = ex / (den[dst] + 1e-16)
+    if attr is not None:
+        ref = ref * attr.double()
+    assert_close(a_seg, ref.float())

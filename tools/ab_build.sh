@@ -4,7 +4,7 @@ set -e
 NAME=$1; SRCS=",$2,"; shift 2
 cd /root/repo/deeprecommendation_amd/csrc
 mkdir -p build/$NAME
-for f in abi gather mlp_fused linear spmm attn attn_split attn_cand mlp_bf16 mlp_bf16_ws8 backward exchange dense_csr probe; do
+for f in abi gather mlp_fused linear spmm attn attn_split attn_cand attn_tail mlp_bf16 mlp_bf16_ws8 backward exchange dense_csr probe; do
   if [[ "$SRCS" == *",$f.hip,"* ]]; then
     EXTRA=""; [[ "$f" == mlp_bf16* ]] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $EXTRA "$@" -c $f.hip -o build/$NAME/$f.hip.o

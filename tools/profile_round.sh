@@ -1,13 +1,13 @@
 #!/bin/bash
 # rocprofv3 passes over every bench context of a round (on the GPU box, from the repo root):
-#   bash tools/profile_round.sh <tag> [contexts...]        default contexts: cfg2 cfg2zipf cfg3 cfg4 cfg5 cfg5_b1048576 cfg5_b4194304
+#   bash tools/profile_round.sh <tag> [contexts...]        default contexts: cfg2 cfg2zipf cfg2_emb128 cfg3 cfg4 cfg5 cfg5_b1048576 cfg5_b4194304
 # Per context: pass 1 kernel trace + stats; passes 2-4 PMC counters, each in its own run (TCC slots: FETCH_SIZE and WRITE_SIZE do
 # not fit one pass; no trace domains besides --kernel-trace beside --pmc).  The profiled command is the bench's own
 # single-context form (in-process, no child processes).  Output: gpurun_out/prof_<tag>_<ctx>/; condensed into
 # profiles/<tag>_<ctx>_* by tools/summarize_profile.py (run here as well, so the summaries travel back with gpurun_out/).
 set -o pipefail
-TAG=${1:-r02}; shift || true
-CTXS=${@:-cfg2 cfg2zipf cfg3 cfg4 cfg5 cfg5_b1048576 cfg5_b4194304}
+TAG=${1:-r03}; shift || true
+CTXS=${@:-cfg2 cfg2zipf cfg2_emb128 cfg3 cfg4 cfg5 cfg5_b1048576 cfg5_b4194304}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd $ROOT
