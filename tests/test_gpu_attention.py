@@ -37,7 +37,7 @@ def test_attention_golden(gpu, name):
     assert_close(out, torch.from_numpy(a["out"]))
     assert_close(att, torch.from_numpy(a["att"]))
     assert_close(out2, torch.from_numpy(a["out"]))          # the plain call converts the dense matrix on the stream and may take other
-    assert_close(out, out2, rtol=2e-6)                      # kernels than the call that returns weights: equal to fp32 rounding
+    assert_close(out, out2)                                 # kernels (attention and MLP) than the call that returns weights: fp32 rounding
     if name.startswith("g3_att_vec"):
         return
     assert float(att[1].abs().sum()) == 0.0   # user without ratings: zeros, not NaN (attention_ncf.py:208-209)
@@ -203,7 +203,7 @@ def test_attention_grouped_equals_per_pair_kernel(native, gpu, mode, A, Fdim, R,
                                          out_bias=bias, pairs_per_wg=ppw)
     # asking for the weights does not change the scores: the weights come from round 2's one-workgroup-per-group kernel, the plain
     # call may take the entry-split kernel (another order of the softmax partial sums): equal to fp32 rounding, not bit for bit
-    assert_close(out_g, out_g2, rtol=2e-6)
+    assert_close(out_g, out_g2)
     ex = SparseRatings(rowptr, col, val, I, pair_row=pair_row).expanded()
     out_p, w_p = native.attn_forward(m, pc, pr, w1 if mode == "mlp" else None, 0.25, ex.rowptr, ex.col, ex.val, feat, out_bias=bias)
     assert w_g.shape == w_p.shape
@@ -574,7 +574,7 @@ def test_attention_forward_dense_matrix_without_host_synchronisation(gpu, name):
         assert_close(out2, ref)
         m.dense_user_matrix_on_stream = False         # round 2's conversion (host reads, exact kernel dispatch): same scores
         out3 = m(cand.clone(), rated, um.clone())
-        assert_close(out3, out2, rtol=2e-6)
+        assert_close(out3, out2)
 
 
 def test_attention_forward_dense_matrix_reference_eval_shape(gpu):
