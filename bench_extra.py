@@ -444,6 +444,10 @@ def run_cfg3(args, ctx):
                                  "peak = 157.3 TFLOP/s fp32 vector = the fp32 MFMA figure"}}
     if distinct is not None:
         line["variants"] = {"distinct_users": distinct}
+        try:
+            line["variants"]["reference_eval_shape"] = _cfg3_reference_eval_shape(device, args)
+        except Exception as exc:  # noqa: BLE001
+            line["variants"]["reference_eval_shape"] = {"error": f"{type(exc).__name__}: {exc}"}
     if not getattr(args, "no_cpu_baseline", False):
         # CPU oracle, reference formulation (materialised candidate x rated pairs, attention_ncf.py:154-213) on a down-scaled
         # sample: 64 pairs of 16 users against those users' own rated items (the full 4096 x 100k pair grid is 2·B·I·IE floats)
@@ -465,6 +469,48 @@ def run_cfg3(args, ctx):
                                 "sample": f"reference formulation on 64 pairs of {users} users x {nnz} rated against their {int(rated_ids.numel())} rated items, "
                                           f"median of 20 forwards after 5 warm-ups ({sec * 1e3:.0f} ms each), torch CPU fp32"}
     return line
+
+
+def _cfg3_reference_eval_shape(device, args):
+    """The reference's OWN evaluation call (eval.py:120-127 -> dynamic_datasets.py:24-40): batch of 512 samples, the union of the batch
+    users' rated items as `rated_items` (I = 1174: the whole catalogue of its dataset), F = 2094 features, a DENSE (512, 1174)
+    user_matrix with a user's row repeated for each of their samples, model dims of the shipped checkpoints (IE = UE = 128, A = 128,
+    MLP [256, 128]).  The dense matrix goes through the on-stream CSR conversion (no host read); CPU baseline = the oracle's
+    reference formulation on the same batch."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
+    F, I, B, users = 2094, 1174, 512, 64
+    torch.manual_seed(21)
+    model = AttentionNCF(item_dim=F, item_emb=128, user_emb=128, att_dense=128, mlp_dense_layers=[256, 128]).eval().to(device)
+    g = torch.Generator(device=device).manual_seed(22)
+    rated = ((torch.rand(I, F, device=device, generator=g) < 0.02).float() + torch.rand(I, F, device=device, generator=g) * 0.1)
+    batches = []
+    for _ in range(4):
+        rows = torch.zeros(users, I, device=device)
+        mask = torch.rand(users, I, device=device, generator=g) < 0.125                  # ~146 rated items per user (SURVEY §6 probe)
+        rows[mask] = (torch.randint(1, 11, (users, I), device=device, generator=g).float() * 0.5 - 2.9)[mask]
+        who = torch.arange(B, device=device) // (B // users)                              # test files are grouped by user
+        cand = rated[torch.randint(0, I, (B,), device=device, generator=g)].contiguous()
+        batches.append((cand, rows[who].contiguous()))
+    with torch.no_grad():
+        def step(k):
+            c, um = batches[k % 4]
+            return model(c, rated, um)
+        wall, warm = _time_steps(step, args.warmup, args.steps)
+        out = step(0)
+    res = {"workload": f"model(candidates ({B}, {F}), rated_items ({I}, {F}), DENSE user_matrix ({B}, {I}): {users} users x {B // users} samples), "
+                       "IE = UE = 128, att_dense = 128, MLP [256, 128]; step enqueued from Python",
+           "pairs_per_s": B * args.steps / wall, "ms_per_step": wall / args.steps * 1e3}
+    if not getattr(args, "no_cpu_baseline", False):
+        from oracle import ncf_oracle as O
+        state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        c0, um0 = batches[0][0].cpu(), batches[0][1].cpu()
+        rated_c = rated.cpu()
+        ref = O.attention_ncf_forward(state, c0, rated_c, um0)
+        res["max_rel_err_vs_oracle"] = float((out.cpu() - ref).abs().max() / ref.abs().max())
+        sec, cores = _cpu_median_s(lambda: O.attention_ncf_forward(state, c0, rated_c, um0), reps=5, warm=1)
+        res["cpu_baseline"] = {"value": B / sec, "unit": "pairs/s", "cores": cores, "kind": "port",
+                               "sample": f"the same batch through the oracle's reference formulation (attention_ncf.py:136-224), median of 5 forwards ({sec * 1e3:.0f} ms each), torch CPU fp32"}
+    return res
 
 
 # ---------------------------------------------------------------------------------------------------- cfg 5
