@@ -27,7 +27,7 @@
 
 #ifndef ATT_SPLIT_DIAG
 #define ATT_SPLIT_DIAG 0   // diagnostic builds (wrong results): 1 = every slot reads pc row 0 (scalar loads all hit), 2 = no tile DMA,
-#endif                     // 3 = no score loop, 4 = no aggregation
+#endif                     // 3 = no score loop, 4 = no aggregation, 5 = 2 + 3 + 4, 6 = exit after the prologue
 #ifndef ATT_SPLIT_DB
 #define ATT_SPLIT_DB 0   // 1: row blocks double buffered in registers (64 VGPRs of rows: spills at the 128-register budget)
 #endif
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
                     ci = sub == 2 ? c2 : (sub == 3 ? c3 : ci);
                 }
                 const int jj = xorj ? (j ^ ((e0p + sub) & 15)) : j;
-                if (ATT_SPLIT_DIAG != 2) dma16(tab + (int64_t)(ci >= 0 ? ci : 0) * ld + 4 * jj, lds_base + (unsigned)piece * 1024u);
+                if (ATT_SPLIT_DIAG != 2 && ATT_SPLIT_DIAG < 5) dma16(tab + (int64_t)(ci >= 0 ? ci : 0) * ld + 4 * jj, lds_base + (unsigned)piece * 1024u);
             }
             return;
         }
@@ -168,6 +168,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
     }
     const int sw = swz ? (lane & 15) : 0;
     const int g4 = lane >> 4, i16 = lane & 15;
+#if ATT_SPLIT_DIAG == 6
+    if (a.nsplit > 0) return;                              // launch + prologue chain only
+#endif
     const float* myrow = prt + lane * A;
     const int NB = A4 / CB;
     for (int64_t t = 0; t < ntiles; ++t) {
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
             }
         };
         auto score_dispatch = [&](const f32x4 (&row)[CB], int blk) {
-            if (ATT_SPLIT_DIAG == 3) return;
+            if (ATT_SPLIT_DIAG == 3 || ATT_SPLIT_DIAG >= 5) return;
             if (np > 2) score_block(row, blk, std::integral_constant<int, 4>{});
             else if (np == 2) score_block(row, blk, std::integral_constant<int, 2>{});
             else if (np == 1) score_block(row, blk, std::integral_constant<int, 1>{});
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
             for (int n = 0; n < NJ; ++n) {
                 const int job = wave + NW * n;
                 const int mt = job % MT, nt = job / MT;
-                if (nt >= NTILES || ATT_SPLIT_DIAG == 4) break;   // wave-uniform
+                if (nt >= NTILES || ATT_SPLIT_DIAG == 4 || ATT_SPLIT_DIAG >= 5) break;   // wave-uniform
                 const f32x4 s4 = *reinterpret_cast<const f32x4*>(scl + 16 * mt + 4 * g4);   // accumulator register i holds pair row 16*mt + 4*g4 + i
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[n][i] *= s4[i];

@@ -24,7 +24,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     out = []
     for ppw, ns in ((32, 4), (32, 1), (64, 2)):
         grouping = (native.group_pairs(who, users, ppw), ppw)
-        fn = lambda: native.attn_forward_grouped(native.ATT_MLP_SCALED, pc, pr, w1, 0.1, rowptr, col, val, who, feat, grouping=grouping, nsplit=ns)
+        fn = lambda: native.attn_forward_grouped(native.ATT_MLP_SCALED, pc, pr, w1, 0.1, rowptr, col, val, who, feat, grouping=grouping, nsplit=ns, leave_partials=True)
         for _ in range(20):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,7 +36,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         out.append(f"ppw={ppw} nsplit={ns}: {e0.elapsed_time(e1) * 10:6.1f} us")
     print(sys.argv[2], "  ".join(out), flush=True)
     sys.exit(0)
-for name in ["", "diag1", "diag2", "diag3", "diag4"]:
+for name in ["", "diag1", "diag2", "diag3", "diag4", "diag5", "diag6"]:
     lib = os.path.join(ROOT, "deeprecommendation_amd", f"libncf_hip_{name}.so" if name else "libncf_hip.so")
     if os.path.exists(lib):
         subprocess.run([sys.executable, __file__, "child", name or "shipped"], env=dict(os.environ, NCF_HIP_LIBRARY=lib))

@@ -24,5 +24,5 @@ rowptr = torch.arange(0, (users + 1) * nnz, nnz, device=dev, dtype=torch.int64)
 who = torch.randint(0, users, (B,), device=dev, generator=g)
 grouping = (native.group_pairs(who, users, ppw), ppw)
 for _ in range(int(os.environ.get("AB_REPS", "40"))):
-    native.attn_forward_grouped(native.ATT_MLP_SCALED, pc, pr, w1, 0.1, rowptr, col, val, who, feat, grouping=grouping, nsplit=ns)
+    native.attn_forward_grouped(native.ATT_MLP_SCALED, pc, pr, w1, 0.1, rowptr, col, val, who, feat, grouping=grouping, nsplit=ns, leave_partials=True)
 torch.cuda.synchronize()
