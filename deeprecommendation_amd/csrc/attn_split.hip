@@ -28,6 +28,13 @@
 #ifndef ATT_SPLIT_DIAG
 #define ATT_SPLIT_DIAG 0   // diagnostic builds (wrong results): 1 = every slot reads pc row 0 (scalar loads all hit), 2 = no tile DMA,
 #endif                     // 3 = no score loop, 4 = no aggregation, 5 = 2 + 3 + 4, 6 = exit after the prologue
+#ifndef ATT_SPLIT_G
+#define ATT_SPLIT_G 1      // 16-byte chunks of pc (per pair) and of w1 per scalar-load step: 1 = 20 SGPRs per step and buffer, 2 = 40
+#endif
+#ifndef ATT_SPLIT_PF
+#define ATT_SPLIT_PF 0     // 1 = the NEXT row block's pc / w1 lines are touched (one scalar load per 64-byte line) when this block starts:
+                           // measured SLOWER (28.2 vs 25.7 us at cfg 3): the extra wait per block costs more than the misses it gathers
+#endif
 #ifndef ATT_SPLIT_DB
 #define ATT_SPLIT_DB 0   // 1: row blocks double buffered in registers (64 VGPRs of rows: spills at the 128-register budget)
 #endif
@@ -168,13 +175,32 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
     }
     const int sw = swz ? (lane & 15) : 0;
     const int g4 = lane >> 4, i16 = lane & 15;
-#if ATT_SPLIT_DIAG == 6
-    if (a.nsplit > 0) return;                              // launch + prologue chain only
-#endif
     const float* myrow = prt + lane * A;
     const int NB = A4 / CB;
+    // Scalar-cache prefetch (ATT_SPLIT_PF, off: measured slower).  A workgroup's pc rows are read exactly once, so every 64-byte line is a
+    // compulsory scalar-cache miss, and with all loads hitting (ablation) the kernel is 5.5 us shorter.  touch_block(b) reads one 16-byte
+    // chunk of every line of row block b with ordinary, compiler-visible scalar loads and throws the values away, so that a block's misses
+    // are taken together.  It did not pay: 28.2 vs 25.7 us.  (A first attempt used inline-asm s_load_dwordx16 into "reserved" SGPRs: hipcc
+    // spilled and reused them under the loads in flight and the kernel hung — scalar loads the compiler cannot see are not an option.)
+    auto touch_block = [&](int blk) {
+#if ATT_SPLIT_PF
+        f32x4 pf[2 * MAXP + 2];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const float* rowp = pcrow[k < np ? k : 0];
+            pf[2 * k] = *(const_f32x4_ptr)(rowp + 32 * blk);
+            pf[2 * k + 1] = *(const_f32x4_ptr)(rowp + 32 * blk + 16);
+        }
+        const float* wp = MODE != 2 ? a.w1 : pcrow[0];
+        pf[2 * MAXP] = *(const_f32x4_ptr)(wp + 32 * blk);
+        pf[2 * MAXP + 1] = *(const_f32x4_ptr)(wp + 32 * blk + 16);
+#pragma unroll
+        for (int i = 0; i < 2 * MAXP + 2; ++i) asm volatile("" ::"s"(pf[i][0]));   // a use: the loads stay, their wait sits here
+#endif
+    };
     for (int64_t t = 0; t < ntiles; ++t) {
         const int64_t e0 = beg + t * EC;
+        touch_block(0);                                    // lands under the DMA wait and the barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of pr(t) / feat(t) have landed (and col / val) ...
         __syncthreads();                                   // ... and everybody's; pid is written
         const bool ok = c_cur >= 0;
@@ -194,42 +220,50 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
         // lgkmcnt(0) (they return out of order), so a step is  wait(step s) -> issue loads(step s+1) -> VALU(step s).
         auto score_block = [&](const f32x4 (&row)[CB], int blk, auto slots) {
             constexpr int NS = decltype(slots)::value;     // slots computed: 1, 2 or 4 (>= np)
-            f32x4 qs[2][NS], ws[2];
-            auto load_step = [&](int st, int slot) {           // constant address space + uniform address = s_load_dwordx4
-                if (MODE != 2) ws[slot] = *(const_f32x4_ptr)(a.w1 + 4 * (blk * CB + st));
+            constexpr int G = ATT_SPLIT_G, NST = CB / G;   // 16-byte chunks per step
+            f32x4 qs[2][NS][G], ws[2][G];
+            auto load_step = [&](int st, int slot) {           // constant address space + uniform address = s_load_dwordx4 / x8
 #pragma unroll
-                for (int k = 0; k < NS; ++k) qs[slot][k] = *(const_f32x4_ptr)(pcrow[k] + 4 * (blk * CB + st));
+                for (int gk = 0; gk < G; ++gk) {
+                    if (MODE != 2) ws[slot][gk] = *(const_f32x4_ptr)(a.w1 + 4 * (blk * CB + st * G + gk));
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) qs[slot][k][gk] = *(const_f32x4_ptr)(pcrow[k] + 4 * (blk * CB + st * G + gk));
+                }
             };
             load_step(0, 0);
 #pragma unroll
-            for (int st = 0; st < CB; ++st) {
+            for (int st = 0; st < NST; ++st) {
                 const int cur = st & 1;
-                asm volatile("" ::"s"(qs[cur][0][0]));     // the compiler's wait for step st sits HERE, before the next issue
+                asm volatile("" ::"s"(qs[cur][0][0][0]));  // the compiler's wait for step st sits HERE, before the next issue
                 __builtin_amdgcn_sched_barrier(0);
-                if (st + 1 < CB) load_step(st + 1, cur ^ 1);
+                if (st + 1 < NST) load_step(st + 1, cur ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const f32x2 p01 = {row[st][0], row[st][1]}, p23 = {row[st][2], row[st][3]};
 #pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const f32x4 q = qs[cur][k];
-                    const f32x2 q01 = {q[0], q[1]}, q23 = {q[2], q[3]};
-                    if (MODE == 0 || MODE == 3) {
-                        const f32x4 ww = ws[cur];
-                        const f32x2 w01 = {ww[0], ww[1]}, w23 = {ww[2], ww[3]};
-                        f32x2 u, v;
-                        if (MODE == 3) {                   // relu(p + q) on 2^-64-scaled operands = the [0, 1] clamp of the packed add
-                            asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(u) : "v"(p01), "s"(q01));
-                            asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(v) : "v"(p23), "s"(q23));
+                for (int gk = 0; gk < G; ++gk) {
+                    const int c = st * G + gk;
+                    const f32x2 p01 = {row[c][0], row[c][1]}, p23 = {row[c][2], row[c][3]};
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const f32x4 q = qs[cur][k][gk];
+                        const f32x2 q01 = {q[0], q[1]}, q23 = {q[2], q[3]};
+                        if (MODE == 0 || MODE == 3) {
+                            const f32x4 ww = ws[cur][gk];
+                            const f32x2 w01 = {ww[0], ww[1]}, w23 = {ww[2], ww[3]};
+                            f32x2 u, v;
+                            if (MODE == 3) {               // relu(p + q) on 2^-64-scaled operands = the [0, 1] clamp of the packed add
+                                asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(u) : "v"(p01), "s"(q01));
+                                asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(v) : "v"(p23), "s"(q23));
+                            } else {
+                                u = p01 + q01, v = p23 + q23;
+                                u = __builtin_elementwise_max(u, (f32x2){0.f, 0.f});
+                                v = __builtin_elementwise_max(v, (f32x2){0.f, 0.f});
+                            }
+                            s2[k] = u * w01 + s2[k];
+                            t2[k] = v * w23 + t2[k];
                         } else {
-                            u = p01 + q01, v = p23 + q23;
-                            u = __builtin_elementwise_max(u, (f32x2){0.f, 0.f});
-                            v = __builtin_elementwise_max(v, (f32x2){0.f, 0.f});
+                            s2[k] = p01 * q01 + s2[k];
+                            t2[k] = p23 * q23 + t2[k];
                         }
-                        s2[k] = u * w01 + s2[k];
-                        t2[k] = v * w23 + t2[k];
-                    } else {
-                        s2[k] = p01 * q01 + s2[k];
-                        t2[k] = p23 * q23 + t2[k];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -258,6 +292,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_split_kernel(const AttnSplitA
         for (int blk = 0; blk < NB; ++blk) {               // four waves per SIMD cover a block's LDS reads
             f32x4 rA[CB];
             read_rows(rA, blk);
+            if (blk + 1 < NB) touch_block(blk + 1);
             score_dispatch(rA, blk);
         }
 #endif
