@@ -23,7 +23,10 @@ def _time_steps(step, warmup, steps, ctx=None):
     milliseconds).  Barrier + synchronize on both sides; the caller takes the max over ranks."""
     t_w = time.perf_counter()
     k = 0
-    while k < warmup or (time.perf_counter() - t_w < 0.03 and k < 2000):
+    # with several ranks the number of warm-up steps must not depend on a rank's own clock: every step of a sharded form is a
+    # collective, and ranks that leave the loop after different counts deadlock
+    fixed = None if (ctx is None or getattr(ctx, "world", 1) == 1) else max(warmup, 50)
+    while (k < fixed) if fixed is not None else (k < warmup or (time.perf_counter() - t_w < 0.03 and k < 2000)):
         step(k)
         k += 1
     if ctx is not None:
