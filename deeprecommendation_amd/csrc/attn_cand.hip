@@ -17,6 +17,10 @@
 #include "group_pairs.h"
 #include <atomic>
 
+#ifndef ATT_CAND_DIAG
+#define ATT_CAND_DIAG 0   // diagnostic builds (wrong results): 1 = W blocks loaded once (no L2 re-reads), 2 = x blocks loaded once, 3 = no MFMAs,
+#endif                    // 4 = no LDS staging (operands = whatever LDS holds)
+
 namespace ncf {
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // rows of x / Wi may be only 4-byte aligned
@@ -82,13 +86,19 @@ __global__ __launch_bounds__(512, 2) void attn_cand_kernel(const CandArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    bool first_load = true;
     auto gload = [&](f32x4 (&va)[2], f32x4 (&vw)[WC], int b) {
+        if (ATT_CAND_DIAG != 2 || first_load) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) va[c] = *reinterpret_cast<const f32x4u*>(ga[c] + 32 * b);
+            for (int c = 0; c < 2; ++c) va[c] = *reinterpret_cast<const f32x4u*>(ga[c] + 32 * b);
+        }
+        if (ATT_CAND_DIAG != 1 || first_load) {
 #pragma unroll
-        for (int c = 0; c < WC; ++c) vw[c] = *reinterpret_cast<const f32x4u*>(gw[c] + 32 * b);
+            for (int c = 0; c < WC; ++c) vw[c] = *reinterpret_cast<const f32x4u*>(gw[c] + 32 * b);
+        }
     };
     auto stage = [&](const f32x4 (&va)[2], const f32x4 (&vw)[WC]) {
+        if (ATT_CAND_DIAG == 4) { asm volatile("" ::"v"(va[0]), "v"(va[1]), "v"(vw[0]), "v"(vw[WC - 1])); return; }
 #pragma unroll
         for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4*>(stA + woA[c]) = va[c];
 #pragma unroll
@@ -102,7 +112,10 @@ __global__ __launch_bounds__(512, 2) void attn_cand_kernel(const CandArgs a) {
             for (int nt = 0; nt < NT; ++nt) {
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(stW + nt * 16 * 32 + ro[h]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc[nt], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    if (ATT_CAND_DIAG == 3) acc[nt][j] += av[j] * wv[j];
+                    else acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc[nt], 0, 0, 0);
+                }
             }
         }
     };
@@ -111,6 +124,7 @@ __global__ __launch_bounds__(512, 2) void attn_cand_kernel(const CandArgs a) {
         const int last = bhi - 1;
         gload(va0, vw0, blo);
         gload(va1, vw1, blo + 1 < bhi ? blo + 1 : last);
+        first_load = false;
         for (int b = blo; b < bhi; b += 2) {                       // two blocks in flight in registers; a step's LDS traffic is its own
             stage(va0, vw0);
             gload(va0, vw0, b + 2 < bhi ? b + 2 : last);           // past the slice: the last block again (harmless, no branch)

@@ -13,6 +13,11 @@
 // No bit-identity with mlp_fused.hip's k order is claimed (another summation order; 1e-5 of the oracle holds).
 #include "ncf_common.h"
 #include "attn_util.h"
+#include <type_traits>
+
+#ifndef ATT_TAIL_DIAG
+#define ATT_TAIL_DIAG 0   // diagnostic builds (wrong results): 1 = no merge (partials not read), 2 = no layers 1 / 2, 3 = exit at once,
+#endif                    // 4 = layers without their weight loads (one fragment reused)
 
 namespace ncf {
 
@@ -38,6 +43,7 @@ __global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g4 = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * TM;
+    if (ATT_TAIL_DIAG == 3) { if (tid == 0) a.out[row0] = 0.f; return; }
 
     // ---- the input tile: cat(candidate_emb, user_emb) (:219, candidate first) ----
     for (int o = tid; o < TM * (K0 / 4); o += 512) {
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs a) {
             v = *reinterpret_cast<const f32x4*>(a.cand + b * a.ldcand + 4 * c);
         } else {
             const int cu = c - EA / 4;
-            if (a.part) {   // out = sum_s O_s e^(m_s - M) / sum_s l_s e^(m_s - M) + bias, slices in index order (attn_combine_kernel's order)
+            if (a.part && ATT_TAIL_DIAG != 1) {   // out = sum_s O_s e^(m_s - M) / sum_s l_s e^(m_s - M) + bias, slices in index order (attn_combine_kernel's order)
                 const float* p0 = a.part + b * a.nsplit * (int64_t)a.ldpart;
                 float M = -INFINITY;
                 for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, p0[(int64_t)s * a.ldpart]);
@@ -65,6 +71,8 @@ __global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs a) {
                 f32x4 bias = {0.f, 0.f, 0.f, 0.f};
                 if (a.ubias) bias = *reinterpret_cast<const f32x4*>(a.ubias + 4 * cu);
                 v = acc * inv + bias;
+            } else if (ATT_TAIL_DIAG == 1) {
+                v = f32x4{0.f, 0.f, 0.f, 0.f};
             } else {
                 v = *reinterpret_cast<const f32x4*>(a.user + b * a.lduser + 4 * cu);
             }
@@ -73,37 +81,80 @@ __global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs a) {
     }
     __syncthreads();
 
-    // one layer: OUT[pair][n] = act(bias[n] + sum_k IN[pair][k] W[n][k]) for this wave's column tiles ct = wave, wave + 8, ...
-    auto layer = [&](const float* in, int ins, int K, const float* __restrict__ W, const float* __restrict__ bias, int N, float* outp, int outs) {
-        const int KB = K / 16;
-        for (int ct = wave; ct < N / 16; ct += NWV) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float* wrow = W + (int64_t)(16 * ct + i16) * K + 4 * g4;
-            const float* irow = in + i16 * ins + 4 * g4;
-            f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow);
-            f32x4 w1 = *reinterpret_cast<const f32x4*>(wrow + (KB > 1 ? 16 : 0));
-            for (int kk = 0; kk < KB; ++kk) {                  // weight fragments two k-blocks ahead (L2 latency under the MFMAs)
-                const f32x4 wv = w0;
-                w0 = w1;
-                w1 = *reinterpret_cast<const f32x4*>(wrow + 16 * (kk + 2 < KB ? kk + 2 : KB - 1));
-                const f32x4 av = *reinterpret_cast<const f32x4*>(irow + 16 * kk);
+    // one layer: OUT[pair][n] = act(bias[n] + sum_k IN[pair][k] W[n][k]); the wave's column tiles ct = wave + 8 t run SIDE BY SIDE (T independent
+    // MFMA chains, their weight fragments in flight together), weight fragments PD k-blocks ahead in a register ring
+    auto layer = [&](auto tiles, const float* in, int ins, int K, const float* __restrict__ W, const float* __restrict__ bias, float* outp, int outs) {
+        constexpr int T = decltype(tiles)::value, PD = 4;
+        constexpr int NA = T == 1 ? 2 : 1;                     // a lone tile runs as two chains (even / odd k-blocks), added at the end: a
+        const int KB = K / 16;                                 // dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles, the pipe takes one per 32
+        f32x4 acc[T][NA], ring[PD][T], aring[PD];
+        const float* wrow[T];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc, 0, 0, 0);
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int c = 0; c < NA; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            wrow[t] = W + (int64_t)(16 * (wave + NWV * t) + i16) * K + 4 * g4;
+        }
+        const float* irow = in + i16 * ins + 4 * g4;
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int kk = d < KB ? d : KB - 1;
+            aring[d] = *reinterpret_cast<const f32x4*>(irow + 16 * kk);      // the activation fragments ride the same ring (LDS latency too)
+#pragma unroll
+            for (int t = 0; t < T; ++t) ring[d][t] = *reinterpret_cast<const f32x4*>(wrow[t] + 16 * kk);
+        }
+        for (int kb = 0; kb < KB; kb += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                const int kk = kb + d;
+                if (kk < KB) {                                 // wave-uniform
+                    f32x4 wv[T];
+                    const f32x4 av = aring[d];
+                    const int kn = kk + PD < KB ? kk + PD : KB - 1;
+                    aring[d] = *reinterpret_cast<const f32x4*>(irow + 16 * kn);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        wv[t] = ring[d][t];
+                        if (ATT_TAIL_DIAG != 4) ring[d][t] = *reinterpret_cast<const f32x4*>(wrow[t] + 16 * kn);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+                            acc[t][d % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[t][j], acc[t][d % NA], 0, 0, 0);
+                }
             }
-            const float bv = bias[16 * ct + i16];
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) outp[(4 * g4 + i) * outs + 16 * ct + i16] = fmaxf(acc[i] + bv, 0.f);   // ReLU (util.py:12-14)
+        for (int t = 0; t < T; ++t) {
+            const int n = 16 * (wave + NWV * t) + i16;
+            const float bv = bias[n];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = NA == 2 ? acc[t][0][i] + acc[t][NA - 1][i] : acc[t][0][i];
+                outp[(4 * g4 + i) * outs + n] = fmaxf(v + bv, 0.f);   // ReLU (util.py:12-14)
+            }
         }
     };
-    layer(xs, XS, K0, a.W1, a.b1, N1, h1, H1S);
+    static_assert(N1 % (16 * NWV) == 0 && N2 % (16 * NWV) == 0, "column tiles are dealt evenly over the waves");
+    if (ATT_TAIL_DIAG != 2) layer(std::integral_constant<int, N1 / 16 / NWV>{}, xs, XS, K0, a.W1, a.b1, h1, H1S);
     __syncthreads();
-    layer(h1, H1S, N1, a.W2, a.b2, N2, h2, H2S);
+    if (ATT_TAIL_DIAG != 2) layer(std::integral_constant<int, N2 / 16 / NWV>{}, h1, H1S, N1, a.W2, a.b2, h2, H2S);
     __syncthreads();
     // last layer (N2 -> 1, no activation): wave 0, lane (pair, quarter): a quarter of the dot each, quarters added in order
     if (wave == 0) {
-        const float* hrow = h2 + i16 * H2S;
+        const float* hrow = h2 + i16 * H2S + g4 * (N2 / 4);
+        const float* wq = a.w3 + g4 * (N2 / 4);
+        f32x4 wv[N2 / 16];
+#pragma unroll
+        for (int c = 0; c < N2 / 16; ++c) wv[c] = *reinterpret_cast<const f32x4*>(wq + 4 * c);   // the quarter's weights at once
         float s = 0.f;
-        for (int k = g4 * (N2 / 4); k < (g4 + 1) * (N2 / 4); ++k) s = fmaf(hrow[k], a.w3[k], s);
+#pragma unroll
+        for (int c = 0; c < N2 / 16; ++c) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + 4 * c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s = fmaf(hv[j], wv[c][j], s);                           // the same k order as a plain loop
+        }
         const float s1 = __shfl(s, i16 + 16), s2 = __shfl(s, i16 + 32), s3 = __shfl(s, i16 + 48);
         if (g4 == 0 && row0 + i16 < a.B) a.out[row0 + i16] = ((s + s1) + (s2 + s3)) + a.b3;
     }
