@@ -335,3 +335,48 @@ def test_bounded_exchange_has_no_host_synchronisation(gpu):
     torch.cuda.synchronize()
     assert all(torch.isfinite(o).all() for o in outs)
     model.check()                                          # (this one synchronises: end of the pass)
+
+
+def _rccl_world1_worker(rank, world, store):
+    """RCCL itself (backend "nccl"), world size 1 — all a one-GPU box can give: the collectives of Comm on DEVICE tensors with the
+    dtypes and shapes the exchange ships (int32 id buckets with equal splits, bf16 / fp32 rows, the MAX of the flags, the fp32 SUM
+    of a node table, a barrier).  At world size 1 every collective is the identity: what is checked is that RCCL takes the calls."""
+    import torch.distributed as dist
+    from deeprecommendation_amd.sharded import Comm
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"file://{store}", rank=rank, world_size=world, device_id=dev)
+    try:
+        comm = Comm()
+        assert comm.backend == "nccl" and comm.world == 1 and not comm._staged(torch.empty(1, device=dev))
+        ids = torch.arange(4 * 65, dtype=torch.int32, device=dev)
+        got = comm.all_to_all(torch.empty_like(ids), ids)
+        rows = torch.randn(4 * 64, 128, device=dev).to(torch.bfloat16)
+        got_rows = comm.all_to_all(torch.empty_like(rows), rows)
+        rows32 = torch.randn(300, 64, device=dev)
+        got32 = comm.all_to_all(torch.empty_like(rows32), rows32, [300], [300])
+        side = torch.cuda.Stream(device=dev)                     # the exchange runs on a second stream
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            got_side = comm.all_to_all(torch.empty_like(ids), ids)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        flags = torch.tensor([0, 1, 0], dtype=torch.int32, device=dev)
+        comm.all_reduce(flags, dist.ReduceOp.MAX)
+        table = torch.randn(1000, 128, device=dev)
+        ref = table.clone()
+        comm.all_reduce(table)
+        dist.barrier(device_ids=[0])
+        torch.cuda.synchronize()
+        assert torch.equal(got, ids) and torch.equal(got_rows, rows) and torch.equal(got32, rows32) and torch.equal(got_side, ids)
+        assert flags.tolist() == [0, 1, 0] and torch.equal(table, ref)
+        assert comm.exchange_blocks(table, [0, 1000]) is table
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_collectives_over_rccl_world1(gpu):
+    import os
+    import tempfile
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rccl_world1_worker, args=(1, os.path.join(d, "store")), nprocs=1, join=True)

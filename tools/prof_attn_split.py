@@ -22,6 +22,8 @@ col = torch.stack([torch.randperm(I, device=dev, generator=g)[:nnz].sort().value
 val = torch.randint(1, 11, (users * nnz,), device=dev, generator=g).float() * 0.5 - 2.9
 rowptr = torch.arange(0, (users + 1) * nnz, nnz, device=dev, dtype=torch.int64)
 who = torch.randint(0, users, (B,), device=dev, generator=g)
+if os.environ.get("AB_EVEN") == "1":      # exactly B / users pairs per user: no partly filled groups
+    who = torch.arange(B, device=dev) % users
 grouping = (native.group_pairs(who, users, ppw), ppw)
 for _ in range(int(os.environ.get("AB_REPS", "40"))):
     native.attn_forward_grouped(native.ATT_MLP_SCALED, pc, pr, w1, 0.1, rowptr, col, val, who, feat, grouping=grouping, nsplit=ns, leave_partials=True)
