@@ -427,7 +427,8 @@ def run_cfg3(args, ctx):
         cand_us = None
         if native.attn_candidates_supported(Fdim, IE, A) and rs is not None:
             prow = rs.pair_row.to(torch.int64).contiguous()
-            cand_us = bench.back_to_back_us(lambda: native.attn_candidates(cand, li.weight.detach(), li.bias.detach(), wc, b0, prow, rs.rowptr.numel() - 1, ppw),
+            wpk = native.PackedCandidateWeight(li.weight.detach())         # what the model's forward uses (packed once per weight version)
+            cand_us = bench.back_to_back_us(lambda: native.attn_candidates(cand, wpk, li.bias.detach(), wc, b0, prow, rs.rowptr.numel() - 1, ppw),
                                             reps=50, settle=5)
         # second workload: every pair its own user (4096 distinct rated sets): nothing to share, the per-pair kernel
         distinct = None

@@ -77,6 +77,10 @@ SIGNATURES = {
     "ncf_attn_candidates_workspace_bytes": (_c_size, [_c_i64]),
     "ncf_attn_candidates": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_i64, _c_p, _c_i64,
                                      _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
+    "ncf_attn_candidates_pack_floats": (_c_size, [_c_int, _c_int]),
+    "ncf_attn_candidates_pack": (_c_int, [_c_p, _c_i64, _c_int, _c_int, _c_p, _c_p]),
+    "ncf_attn_candidates_packed": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_i64, _c_p, _c_i64,
+                                            _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
     "ncf_attn_split_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
     "ncf_attn_split_workspace_bytes": (_c_size, [_c_i64, _c_int, _c_int]),
     "ncf_attn_forward_split": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, ctypes.c_float, _c_p, _c_p, _c_p,
@@ -782,17 +786,44 @@ def attn_candidates_supported(K: int, N1: int, N2: int) -> bool:
     return bool(load_library().ncf_attn_candidates_supported(int(K), int(N1), int(N2)))
 
 
-def attn_candidates(x: torch.Tensor, Wi: torch.Tensor, bi: Optional[torch.Tensor], Wc: torch.Tensor, b0: Optional[torch.Tensor],
+class PackedCandidateWeight:
+    """ItemEmbeddings' (N1, K) weight in MFMA operand order for attn_candidates (ncf_attn_candidates_pack): built once per weight
+    version (the model keeps it beside its other weight-derived caches)."""
+
+    def __init__(self, Wi: torch.Tensor):
+        lib = load_library()
+        _dev(Wi, "Wi")
+        if Wi.dtype != torch.float32:
+            raise TypeError("attn_candidates computes in fp32")
+        self.N1, self.K, ldw = _rows2d(Wi, "Wi")
+        self.src = Wi
+        # N1 = 128: the packed kernel holds half a step less in flight than the LDS-staged one and measured slower at the reference's
+        # evaluation batch (33.3 vs 29.7 us at B = 512): attn_candidates() takes the unpacked entry point there
+        self.use_packed = self.N1 == 64
+        self.data = None
+        if self.use_packed:
+            self.data = torch.empty(lib.ncf_attn_candidates_pack_floats(self.K, self.N1), dtype=torch.float32, device=Wi.device)
+            _check(lib.ncf_attn_candidates_pack(_ptr(Wi), ldw, self.K, self.N1, _ptr(self.data), _stream(Wi)))
+
+
+def attn_candidates(x: torch.Tensor, Wi, bi: Optional[torch.Tensor], Wc: torch.Tensor, b0: Optional[torch.Tensor],
                     pair_row: Optional[torch.Tensor] = None, n_rows: int = 0, pairs_per_wg: int = 32):
     """ncf_attn_candidates: (emb (B, N1), pc (B, N2), grouping or None) — the candidates' ItemEmbeddings and their half of
     AttentionNet.0 in one launch; with ``pair_row`` (B,) int64 the same launch also lists the pairs by rated set (the ``Grouping``
-    group_pairs() returns).  Shapes: attn_candidates_supported(); the fused grouping needs B, n_rows <= 32768."""
+    group_pairs() returns).  ``Wi``: the (N1, K) weight, or a PackedCandidateWeight of it (ncf_attn_candidates_packed: the faster
+    form, bit-identical results).  Shapes: attn_candidates_supported(); the fused grouping needs B, n_rows <= 32768."""
     lib = load_library()
     _dev(x, "x")
-    if x.dtype != torch.float32 or Wi.dtype != torch.float32 or Wc.dtype != torch.float32:
+    if isinstance(Wi, PackedCandidateWeight) and not Wi.use_packed:
+        Wi = Wi.src
+    packed = isinstance(Wi, PackedCandidateWeight)
+    if x.dtype != torch.float32 or (not packed and Wi.dtype != torch.float32) or Wc.dtype != torch.float32:
         raise TypeError("attn_candidates computes in fp32")
     B, K, ldx = _rows2d(x, "x")
-    N1, K2, ldw = _rows2d(Wi, "Wi")
+    if packed:
+        N1, K2, ldw = Wi.N1, Wi.K, 0
+    else:
+        N1, K2, ldw = _rows2d(Wi, "Wi")
     N2 = int(Wc.shape[0])
     if K2 != K or Wc.shape[1] != N1 or not Wc.is_contiguous():
         raise ValueError("attn_candidates: Wi must be (N1, K) and Wc contiguous (N2, N1)")
@@ -813,9 +844,13 @@ def attn_candidates(x: torch.Tensor, Wi: torch.Tensor, bi: Optional[torch.Tensor
         nbytes = lib.ncf_attn_candidates_workspace_bytes(R)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         grp = Grouping(grp_ptr, pair_ids[:B], wg_ptr, wg_row)
-    _check(lib.ncf_attn_candidates(_ptr(x), B, ldx, K, _ptr(Wi), ldw, _ptr(bi), N1, _ptr(Wc), _ptr(b0), N2, _ptr(emb), emb.stride(0),
-                                   _ptr(pc), pc.stride(0), _ptr(pair_row), R, int(pairs_per_wg), _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr),
-                                   _ptr(wg_row), _ptr(ws), nbytes, _ptr(_oob_flag(dev)) if pair_row is not None else None, _stream(x)))
+    tail = (_ptr(bi), N1, _ptr(Wc), _ptr(b0), N2, _ptr(emb), emb.stride(0), _ptr(pc), pc.stride(0), _ptr(pair_row), R, int(pairs_per_wg),
+            _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr), _ptr(wg_row), _ptr(ws), nbytes,
+            _ptr(_oob_flag(dev)) if pair_row is not None else None, _stream(x))
+    if packed:
+        _check(lib.ncf_attn_candidates_packed(_ptr(x), B, ldx, K, _ptr(Wi.data), *tail))
+    else:
+        _check(lib.ncf_attn_candidates(_ptr(x), B, ldx, K, _ptr(Wi), ldw, *tail))
     return emb, pc, grp
 
 

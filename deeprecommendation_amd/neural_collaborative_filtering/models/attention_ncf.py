@@ -295,8 +295,10 @@ class AttentionNCF(_ScoringMixin, NCF):
                 R = ratings.rowptr.numel() - 1
                 fuse_grouping = grouped and not return_attention_weights and B <= 32768 and R <= 32768
                 ppw = native.default_pairs_per_wg(B)
+                if "cand_packed" not in cache:       # ItemEmbeddings' weight in MFMA operand order: once per weight version
+                    cache["cand_packed"] = native.PackedCandidateWeight(li.weight.detach())
                 cand_emb, pc, grouping = native.attn_candidates(
-                    candidate_items.float().contiguous(), li.weight.detach(), li.bias.detach(), wc, b0,
+                    candidate_items.float().contiguous(), cache["cand_packed"], li.bias.detach(), wc, b0,
                     ratings.pair_row.to(torch.int64).contiguous() if fuse_grouping else None, R, ppw)
                 if grouping is not None:
                     grouping = (grouping, ppw)

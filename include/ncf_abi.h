@@ -437,6 +437,20 @@ int ncf_attn_candidates(const float* dev_x, int64_t B, int64_t ldx, int K,
                         int64_t* dev_grp_ptr, int64_t* dev_pair_ids, int64_t* dev_wg_ptr, int32_t* dev_wg_row,
                         void* dev_workspace, size_t workspace_bytes, int32_t* dev_oob_flag, ncf_stream_t stream);
 
+/* The same launch with ItemEmbeddings' weight PRE-PACKED in MFMA operand order (once per weight version: ncf_attn_candidates_pack
+ * into ncf_attn_candidates_pack_floats(K, N1) floats, 16-byte aligned).  Every weight load is then one contiguous 1 KB run straight
+ * into operand registers: the kernel fits two workgroups per CU, so the grouping workgroup runs beside a row tile instead of in front
+ * of one.  Same arguments otherwise (no ldw), bit-identical emb / pc. */
+size_t ncf_attn_candidates_pack_floats(int K, int N1);
+int ncf_attn_candidates_pack(const float* dev_Wi, int64_t ldw, int K, int N1, float* dev_packed, ncf_stream_t stream);
+int ncf_attn_candidates_packed(const float* dev_x, int64_t B, int64_t ldx, int K,
+                               const float* dev_Wi_packed, const float* dev_bi, int N1,
+                               const float* dev_Wc, const float* dev_b0, int N2,
+                               float* dev_emb, int64_t ldemb, float* dev_pc, int64_t ldpc,
+                               const int64_t* dev_pair_row, int64_t n_rows, int pairs_per_wg,
+                               int64_t* dev_grp_ptr, int64_t* dev_pair_ids, int64_t* dev_wg_ptr, int32_t* dev_wg_row,
+                               void* dev_workspace, size_t workspace_bytes, int32_t* dev_oob_flag, ncf_stream_t stream);
+
 /* out[r, :] = x[r, :] / max(||x[r, :]||_2, 1e-12) — torch.nn.functional.normalize(p=2, dim=1) of the cosine
  * variant, models/attention_ncf.py:167-168. */
 int ncf_l2_normalize_rows(const float* dev_x, int64_t ldx, int64_t R, int E, float* dev_out, int64_t ldout,

@@ -642,3 +642,43 @@ def test_attention_tail_kernel(gpu, E, B, nsplit):
     out2 = native.attn_tail(cand, native.AttnPartials(ws, nsplit, E, B), ubias, W1, b1, W2, b2, w3, b3)
     assert_close(out2, mlp64(torch.cat((cand.double(), ue), 1)))
     assert torch.equal(out2, native.attn_tail(cand, native.AttnPartials(ws, nsplit, E, B), ubias, W1, b1, W2, b2, w3, b3))
+
+
+@pytest.mark.parametrize("B,K,N1,N2,users", [(4096, 2094, 64, 128, 64), (100, 2094, 128, 128, 7), (33, 96, 64, 16, 3), (17, 31, 64, 32, 17),
+                                               (512, 1000, 128, 256, 1), (1, 65, 64, 64, 1)])
+def test_attn_candidates_both_weight_forms(gpu, B, K, N1, N2, users):
+    """ncf_attn_candidates / ncf_attn_candidates_packed (candidate ItemEmbeddings + candidate half of AttentionNet.0 + the listing of
+    the pairs by rated set in one launch): both against an fp64 product, bit-identical to each other, grouping = ncf_group_pairs_rows'.
+    Ragged K (2094 = 65 * 32 + 14; 31 < one step), B not a multiple of the 16-row tile, both widths of ItemEmbeddings."""
+    from deeprecommendation_amd import native
+    g = torch.Generator().manual_seed(B + K)
+    x = ((torch.rand(B, K, generator=g) < 0.1).float() + torch.rand(B, K, generator=g) * 0.1).to(gpu)
+    Wi = (torch.randn(N1, K, generator=g) / K ** 0.5).to(gpu)
+    bi = (torch.randn(N1, generator=g) * 0.1).to(gpu)
+    Wc = (torch.randn(N2, N1, generator=g) / N1 ** 0.5).to(gpu)
+    b0 = (torch.randn(N2, generator=g) * 0.1).to(gpu)
+    who = torch.randint(0, users, (B,), generator=g).to(gpu)
+    ppw = 32
+    e64 = x.double() @ Wi.double().t() + bi.double()
+    p64 = e64 @ Wc.double().t() + b0.double()
+    emb, pc, grp = native.attn_candidates(x, Wi, bi, Wc, b0, who, users, ppw)
+    wpk = native.PackedCandidateWeight(Wi)
+    if not wpk.use_packed:                                      # N1 = 128: the wrapper prefers the unpacked kernel; test the packed one anyway
+        lib = native.load_library()
+        wpk.data = torch.empty(lib.ncf_attn_candidates_pack_floats(K, N1), dtype=torch.float32, device=gpu)
+        assert lib.ncf_attn_candidates_pack(Wi.data_ptr(), Wi.stride(0), K, N1, wpk.data.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        wpk.use_packed = True
+    emb2, pc2, grp2 = native.attn_candidates(x, wpk, bi, Wc, b0, who, users, ppw)
+    emb3, pc3, none = native.attn_candidates(x, wpk, bi, Wc, b0)
+    assert none is None
+    assert_close(emb, e64.float())
+    assert_close(pc, p64.float())
+    assert torch.equal(emb2, emb) and torch.equal(pc2, pc) and torch.equal(emb3, emb) and torch.equal(pc3, pc)
+    ref = native.group_pairs(who, users, ppw)
+    n_wg = int(ref[2][-1])
+    for gg in (grp, grp2):
+        assert torch.equal(gg[0], ref[0]) and torch.equal(gg[2], ref[2]) and torch.equal(gg.wg_row[:n_wg], ref.wg_row[:n_wg])
+        gp = ref[0].tolist()
+        for r in range(users):                                  # the same SET of pairs per row (their order comes from atomics)
+            assert sorted(gg[1][gp[r]:gp[r + 1]].tolist()) == sorted(ref[1][gp[r]:gp[r + 1]].tolist())
+    native.check_oob(gpu)

@@ -52,6 +52,11 @@ def case(B=4096, K=2094, N1=64, N2=128, users=64, ppw=32):
     emb2, pc2, _ = native.attn_candidates(x, Wi, bi, Wc, b0, who, users, ppw)
     t_new = per_launch(lambda: native.attn_candidates(x, Wi, bi, Wc, b0, who, users, ppw))
     t_new_ng = per_launch(lambda: native.attn_candidates(x, Wi, bi, Wc, b0))
+    wpk = native.PackedCandidateWeight(Wi)
+    emb3, pc3, grp3 = native.attn_candidates(x, wpk, bi, Wc, b0, who, users, ppw)
+    t_pk = per_launch(lambda: native.attn_candidates(x, wpk, bi, Wc, b0, who, users, ppw))
+    t_pk_ng = per_launch(lambda: native.attn_candidates(x, wpk, bi, Wc, b0))
+    print(f"   packed Wi: {t_pk:6.1f} us (no grouping {t_pk_ng:6.1f}) bit-identical {torch.equal(emb3, emb) and torch.equal(pc3, pc)}", flush=True)
     t_l1 = per_launch(lambda: native.linear(x, Wi, bi))
     t_l2 = per_launch(lambda: native.linear(e_ref, Wc, b0))
     t_g = per_launch(lambda: native.group_pairs(who, users, ppw))
