@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512, 4) void attn_cand_packed_kernel(const CandArgs
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool grouping = a.pair_row != nullptr;
-    if (grouping && blockIdx.x == 0) {                             // shares its CU with a row tile now: no priority games needed
+    if (grouping && blockIdx.x == 0) {                             // shares its CU with a row tile now (priority 3 changes nothing: 20.2 vs 20.3 us)
         int* lds = reinterpret_cast<int*>(smem_f);
         if (a.R <= kGroupLdsRows)
             group_small_body<true, 512>(a.pair_row, a.B, a.R, a.ppw, a.gcounts, a.gcursor, a.bad, a.grp_ptr, a.wg_ptr, a.pair_ids, a.wg_row, lds);

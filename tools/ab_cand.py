@@ -74,8 +74,13 @@ if __name__ == "__main__":
         Wc = (torch.randn(N2, N1, device=dev, generator=g) / N1 ** 0.5).contiguous()
         b0 = torch.randn(N2, device=dev, generator=g) * 0.1
         who = torch.randint(0, users, (B,), device=dev, generator=g)
+        wpk = native.PackedCandidateWeight(Wi)
         for _ in range(60):
-            if sys.argv[2] == "fused":
+            if sys.argv[2] == "packed":
+                native.attn_candidates(x, wpk, bi, Wc, b0, who, users, ppw)
+            elif sys.argv[2] == "packed_ng":
+                native.attn_candidates(x, wpk, bi, Wc, b0)
+            elif sys.argv[2] == "fused":
                 native.attn_candidates(x, Wi, bi, Wc, b0, who, users, ppw)
             elif sys.argv[2] == "fused_ng":
                 native.attn_candidates(x, Wi, bi, Wc, b0)
