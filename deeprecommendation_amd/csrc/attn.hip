@@ -1253,7 +1253,7 @@ extern "C" int ncf_group_pairs_rows(const int64_t* pair_row, int64_t B, int64_t 
         else hipLaunchKernelGGL(group_small_kernel<false>, dim3(1), dim3(1024), 0, s, pair_row, B, R, pairs_per_wg, counts, cursor, bad, grp_ptr, wg_ptr, pair_ids, wg_row);
         return check_launch("ncf_group_pairs");
     }
-    if (hipMemsetAsync(workspace, 0, ncf_group_pairs_workspace_bytes(R), s) != hipSuccess) return check_launch("ncf_group_pairs(memset)");
+    fill_u32_async(workspace, 0u, ncf_group_pairs_workspace_bytes(R), s);
     if (B > 0) hipLaunchKernelGGL(group_count_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, pair_row, B, R, counts, bad);
     hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, s, counts, R, pairs_per_wg, grp_ptr, wg_ptr, cursor, wg_row);
     if (B > 0) hipLaunchKernelGGL(group_scatter_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, pair_row, B, R, cursor, pair_ids);

@@ -227,7 +227,10 @@ extern "C" int ncf_gemm_tn(const float* A, int64_t lda, const float* Bm, int64_t
                            int64_t ldo, void* workspace, size_t ws_bytes, ncf_stream_t stream) {
     if (N1 <= 0 || N2 <= 0 || M < 0 || !out || ldo < N2) return fail(NCF_EINVAL, "ncf_gemm_tn: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    if (M == 0) return hipMemset2DAsync(out, ldo * sizeof(float), 0, N2 * sizeof(float), N1, s) == hipSuccess ? NCF_OK : fail(NCF_ELAUNCH, "ncf_gemm_tn: memset failed");
+    if (M == 0) {                                              // an empty batch: the gradient is zero (a kernel, not a memset: ncf_common.h)
+        for (int r = 0; r < N1; ++r) fill_u32_async(out + (int64_t)r * ldo, 0u, (size_t)N2 * sizeof(float), s);
+        return check_launch("ncf_gemm_tn (empty)");
+    }
     if (!A || !Bm || lda < N1 || ldb < N2) return fail(NCF_EINVAL, "ncf_gemm_tn: bad operand");
     const size_t need = ncf_gemm_tn_workspace_bytes(M, N1, N2);
     if (!workspace || ws_bytes < need) return fail(NCF_EWORKSPACE, "ncf_gemm_tn: workspace %zu < %zu bytes", ws_bytes, need);
@@ -257,7 +260,7 @@ extern "C" size_t ncf_colsum_workspace_bytes(int64_t M, int N) {
 extern "C" int ncf_colsum(const float* X, int64_t ldx, int64_t M, int N, float* out, void* workspace, size_t ws_bytes, ncf_stream_t stream) {
     if (N <= 0 || M < 0 || !out || (M > 0 && (!X || ldx < N))) return fail(NCF_EINVAL, "ncf_colsum: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    if (M == 0) return hipMemsetAsync(out, 0, N * sizeof(float), s) == hipSuccess ? NCF_OK : fail(NCF_ELAUNCH, "ncf_colsum: memset failed");
+    if (M == 0) { fill_u32_async(out, 0u, (size_t)N * sizeof(float), s); return check_launch("ncf_colsum (empty)"); }
     const size_t need = ncf_colsum_workspace_bytes(M, N);
     if (!workspace || ws_bytes < need) return fail(NCF_EWORKSPACE, "ncf_colsum: workspace %zu < %zu bytes", ws_bytes, need);
     const int64_t slices = colsum_slices(M);

@@ -175,8 +175,8 @@ extern "C" int ncf_dense_csr_rows(const float* um, int64_t ld, int64_t B, int64_
     const unsigned wblocks = (unsigned)((B + 3) / 4);
     hipLaunchKernelGGL(dense_row_scan_kernel, dim3(wblocks), dim3(256), 0, s, um, ld, B, I, w.cnt, w.hash);
     if (share_rows) {
-        if (hipMemsetAsync(w.hkeys, 0xFF, w.H * 8, s) != hipSuccess || hipMemsetAsync(w.hrep, 0x7F, w.H * 4, s) != hipSuccess)
-            return check_launch("ncf_dense_csr_rows (memset)");
+        fill_u32_async(w.hkeys, 0xFFFFFFFFu, w.H * 8, s);          // by kernels, not hipMemsetAsync: ncf_common.h
+        fill_u32_async(w.hrep, 0x7F7F7F7Fu, w.H * 4, s);
         hipLaunchKernelGGL(row_rep_insert_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, w.hash, B, w.hkeys, w.hrep, (int64_t)w.H - 1, w.pos);
         hipLaunchKernelGGL(row_rep_verify_kernel, dim3(wblocks), dim3(256), 0, s, um, ld, B, I, w.hrep, w.pos, w.cnt, pair_row, keep_cnt);
     } else {

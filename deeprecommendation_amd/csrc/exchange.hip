@@ -207,9 +207,8 @@ extern "C" int ncf_bucket_ids(const int64_t* idx, int64_t B, int64_t rows_per_ra
     if (!send || !counts || (B > 0 && (!idx || !slot))) return fail(NCF_EINVAL, "ncf_bucket_ids: null pointer");
     hipStream_t s = (hipStream_t)stream;
     // padding slots name local row 0 (a valid row wherever the shard is not empty): the owner gathers them like any other
-    if (hipMemsetAsync(send, 0, sizeof(int64_t) * (size_t)world * (size_t)cap, s) != hipSuccess ||
-        hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)world, s) != hipSuccess)
-        return check_launch("ncf_bucket_ids (memset)");
+    fill_u32_async(send, 0u, sizeof(int64_t) * (size_t)world * (size_t)cap, s);
+    fill_u32_async(counts, 0u, sizeof(int32_t) * (size_t)world, s);
     if (B == 0) return NCF_OK;
     const int64_t per_block = kBucketThreads * kBucketPerThread;
     const int64_t blocks = (B + per_block - 1) / per_block;
@@ -236,9 +235,8 @@ extern "C" int ncf_bucket_ids_dedup(const int64_t* idx, int64_t B, int64_t rows_
         return fail(NCF_EWORKSPACE, "ncf_bucket_ids_dedup: the hash table needs a power of two of at least ncf_bucket_dedup_table_slots(B) slots");
     hipStream_t s = (hipStream_t)stream;
     const int64_t used = (int64_t)ncf_bucket_dedup_table_slots(B);   // only this prefix of the table is touched
-    if (hipMemsetAsync(hkeys, 0xFF, sizeof(int64_t) * (size_t)used, s) != hipSuccess ||
-        hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)world, s) != hipSuccess)
-        return check_launch("ncf_bucket_ids_dedup (memset)");
+    fill_u32_async(hkeys, 0xFFFFFFFFu, sizeof(int64_t) * (size_t)used, s);
+    fill_u32_async(counts, 0u, sizeof(int32_t) * (size_t)world, s);
     const int64_t per_block = kBucketThreads * kBucketPerThread;
     if (B > 0) {
         const int64_t blocks = (B + per_block - 1) / per_block;

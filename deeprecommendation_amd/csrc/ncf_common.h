@@ -38,6 +38,18 @@ int num_cus();
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Stream-ordered fill of 32-bit words BY A KERNEL.  hipMemsetAsync is not used in this library: captured into a HIP graph, memset
+// nodes and the kernel nodes around them lost their order from the second back-to-back replay on (ROCm 7.2 — a replayed
+// dense-user_matrix forward hung in the hash-table probe; tools/graph_dense_probe.py); kernel nodes keep it.
+static __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+inline void fill_u32_async(void* p, uint32_t v, size_t nbytes, hipStream_t s) {   // nbytes: a multiple of 4
+    const size_t n = nbytes / 4;
+    if (n) hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint32_t*)p, v, n);
+}
+
 constexpr int kWave = 64;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -682,3 +682,43 @@ def test_attn_candidates_both_weight_forms(gpu, B, K, N1, N2, users):
         for r in range(users):                                  # the same SET of pairs per row (their order comes from atomics)
             assert sorted(gg[1][gp[r]:gp[r + 1]].tolist()) == sorted(ref[1][gp[r]:gp[r + 1]].tolist())
     native.check_oob(gpu)
+
+
+def test_dense_user_matrix_forward_replays_as_a_hip_graph(gpu):
+    """The reference's call shape (dense user_matrix, on-stream CSR conversion with its hash table) captured into ONE HIP graph and
+    replayed back to back: equal to the eager forward every time.  (The table used to be cleared by hipMemsetAsync: as graph nodes the
+    memsets and the kernels around them lost their order from the second back-to-back replay on and the probe loop never ended —
+    the library now clears with a kernel, ncf_common.h.)"""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF
+    torch.manual_seed(5)
+    F, I, B, users = 96, 300, 256, 16
+    m = AttentionNCF(item_dim=F, item_emb=64, user_emb=64, att_dense=32, mlp_dense_layers=[256, 128]).eval().to(gpu)
+    g = torch.Generator().manual_seed(6)
+    rated = (torch.rand(I, F, generator=g) < 0.2).float().to(gpu)
+    rows = torch.zeros(users, I)
+    mask = torch.rand(users, I, generator=g) < 0.2
+    rows[mask] = (torch.randint(1, 11, (users, I), generator=g).float() * 0.5 - 2.9)[mask]
+    um = rows[torch.arange(B) // (B // users)].contiguous().to(gpu)
+    cand = rated[torch.randint(0, I, (B,), generator=g).to(gpu)].contiguous()
+    with torch.no_grad():
+        ref = m(cand, rated, um).clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m(cand, rated, um)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            out = m(cand, rated, um)
+        for _ in range(12):
+            gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        um2 = um.roll(B // users, 0).contiguous()                 # other users' rows into the captured buffer, then replay
+        ref2 = m(cand, rated, um2).clone()
+        um.copy_(um2)
+        for _ in range(3):
+            gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref2)
