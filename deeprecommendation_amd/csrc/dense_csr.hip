@@ -5,10 +5,11 @@
 // (neural_collaborative_filtering/datasets/dynamic_datasets.py:24-40) — the web backend repeats ONE row for every candidate
 // (webapp/backend.py:78-121).  The attention kernels want CSR, and the grouped kernels want equal rows to SHARE one CSR row.
 // Round 2 did that with torch ops and two host reads (a float64 projection of the matrix, torch.unique, int(), bool()).
-// Here: five small kernels and one cumulative sum, no size ever read by the host.
-//   1. dense_row_scan      one wave per row: number of non-zero entries + a 64-bit hash of the row's (column, value) set
-//   2. row_rep_insert      hash -> slot of an open-addressing table (atomicCAS on the key); payload = atomicMin of the pair index:
-//                          the SMALLEST pair index with that hash is the candidate representative (deterministic)
+// Here: four small kernels and one cumulative sum (in place), no size ever read by the host.
+//   0. row_rep_clear       the hash table's empty state (a kernel, not hipMemsetAsync: ncf_common.h)
+//   1. dense_row_scan      one wave per row: number of non-zero entries + a 64-bit hash of the row's (column, value) set, and (same
+//                          launch) hash -> slot of an open-addressing table (atomicCAS on the key); payload = atomicMin of the pair
+//                          index: the SMALLEST pair index with that hash is the candidate representative (deterministic)
 //   3. row_rep_verify      one wave per row: the row is compared with its candidate's, element by element; equal -> it shares the
 //                          candidate's CSR row and lists no entries itself; different (a hash collision) -> it represents itself.
 //                          Correctness never rests on the hash.
@@ -37,7 +38,8 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 }
 
 __global__ __launch_bounds__(256) void dense_row_scan_kernel(const float* __restrict__ um, int64_t ld, int64_t B, int64_t I,
-                                                             int32_t* __restrict__ cnt, uint64_t* __restrict__ hash) {
+                                                             int32_t* __restrict__ cnt, unsigned long long* __restrict__ hkeys,
+                                                             int* __restrict__ hrep, int64_t hmask, int64_t* __restrict__ pos) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -56,23 +58,23 @@ __global__ __launch_bounds__(256) void dense_row_scan_kernel(const float* __rest
     h = wave_sum_u64(h);
     if (lane == 0) {
         cnt[b] = n;
-        hash[b] = h == ~0ull ? 0ull : h;                      // ~0 is the table's empty key
+        if (hkeys) {                                          // step 2 in the same launch: the row's hash into the table (cleared by the launch before)
+            const unsigned long long key = h == ~0ull ? 0ull : h;     // ~0 is the table's empty key
+            int64_t slot = (int64_t)(dmix64(key) & (uint64_t)hmask);
+            for (;;) {
+                const unsigned long long old = atomicCAS(&hkeys[slot], ~0ull, key);
+                if (old == ~0ull || old == key) break;
+                slot = (slot + 1) & hmask;
+            }
+            atomicMin(&hrep[slot], (int)b);
+            pos[b] = slot;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void row_rep_insert_kernel(const uint64_t* __restrict__ hash, int64_t B, unsigned long long* __restrict__ hkeys,
-                                                             int* __restrict__ hrep, int64_t hmask, int64_t* __restrict__ pos) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const unsigned long long key = hash[b];
-    int64_t h = (int64_t)(dmix64(key) & (uint64_t)hmask);
-    for (;;) {
-        const unsigned long long old = atomicCAS(&hkeys[h], ~0ull, key);
-        if (old == ~0ull || old == key) break;
-        h = (h + 1) & hmask;
-    }
-    atomicMin(&hrep[h], (int)b);
-    pos[b] = h;
+__global__ __launch_bounds__(256) void row_rep_clear_kernel(unsigned long long* __restrict__ hkeys, int* __restrict__ hrep, int64_t H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H) { hkeys[i] = ~0ull; hrep[i] = 0x7F7F7F7F; }
 }
 
 __global__ __launch_bounds__(256) void row_rep_verify_kernel(const float* __restrict__ um, int64_t ld, int64_t B, int64_t I,
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(256) void row_rep_verify_kernel(const float* __rest
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
+    if (b == 0 && lane == 0) keep_cnt[-1] = 0;                 // keep_cnt = rowptr + 1: the cumulative sum runs in place, rowptr[0] = 0
     int64_t rep = hrep[pos[b]];
     if (rep != b) {
         const float* r0 = um + b * ld;
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256) void row_rep_verify_kernel(const float* __rest
 __global__ __launch_bounds__(256) void rows_self_kernel(int64_t B, const int32_t* __restrict__ cnt, int64_t* __restrict__ pair_row,
                                                         int64_t* __restrict__ keep_cnt) {   // no sharing: every row represents itself
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) keep_cnt[-1] = 0;
     if (b < B) { pair_row[b] = b; keep_cnt[b] = cnt[b]; }
 }
 
@@ -137,7 +141,7 @@ extern "C" size_t ncf_dense_csr_table_slots(int64_t B) {
     return h;
 }
 
-/* workspace: cnt int32[B] | hash u64[B] | pos i64[B] | hkeys u64[H] | hrep int32[H]   (H = ncf_dense_csr_table_slots(B)) */
+/* workspace: cnt int32[B] | (unused) u64[B] | pos i64[B] | hkeys u64[H] | hrep int32[H]   (H = ncf_dense_csr_table_slots(B)) */
 extern "C" size_t ncf_dense_csr_workspace_bytes(int64_t B) {
     const size_t b = (size_t)(B > 0 ? B : 0), h = ncf_dense_csr_table_slots(B);
     return ((b * 4 + 15) / 16) * 16 + b * 8 + b * 8 + h * 8 + h * 4;
@@ -161,11 +165,16 @@ DenseWs carve(void* ws, int64_t B) {
 }
 }  // namespace
 
-/* Phase 1 (everything before the cumulative sum): pair_row (B) and keep_cnt (B) = entries each row will list. */
-extern "C" int ncf_dense_csr_rows(const float* um, int64_t ld, int64_t B, int64_t I, int share_rows, int64_t* pair_row, int64_t* keep_cnt,
+/* Phase 1 (everything before the cumulative sum): pair_row (B) and rowptr (B + 1) = [0, entries row 0 will list, entries row 1 will
+ * list, ...]: the caller's inclusive cumulative sum over rowptr, IN PLACE, turns it into the CSR's rowptr. */
+extern "C" int ncf_dense_csr_rows(const float* um, int64_t ld, int64_t B, int64_t I, int share_rows, int64_t* pair_row, int64_t* rowptr,
                                   void* workspace, size_t workspace_bytes, ncf_stream_t stream) {
+    int64_t* const keep_cnt = rowptr ? rowptr + 1 : nullptr;
     if (B < 0 || I < 0 || ld < I) return fail(NCF_EINVAL, "ncf_dense_csr_rows: bad sizes");
-    if (B == 0) return NCF_OK;
+    if (B == 0) {
+        if (rowptr) fill_u32_async(rowptr, 0u, sizeof(int64_t), (hipStream_t)stream);
+        return check_launch("ncf_dense_csr_rows (empty)");
+    }
     if (B >= (1ll << 31) || I >= (1ll << 31)) return fail(NCF_EUNSUPPORTED, "ncf_dense_csr_rows: more than 2^31 rows or columns");
     if (!um || !pair_row || !keep_cnt || !workspace) return fail(NCF_EINVAL, "ncf_dense_csr_rows: null pointer");
     if (workspace_bytes < ncf_dense_csr_workspace_bytes(B) || !aligned16(workspace))
@@ -173,13 +182,12 @@ extern "C" int ncf_dense_csr_rows(const float* um, int64_t ld, int64_t B, int64_
     hipStream_t s = (hipStream_t)stream;
     DenseWs w = carve(workspace, B);
     const unsigned wblocks = (unsigned)((B + 3) / 4);
-    hipLaunchKernelGGL(dense_row_scan_kernel, dim3(wblocks), dim3(256), 0, s, um, ld, B, I, w.cnt, w.hash);
     if (share_rows) {
-        fill_u32_async(w.hkeys, 0xFFFFFFFFu, w.H * 8, s);          // by kernels, not hipMemsetAsync: ncf_common.h
-        fill_u32_async(w.hrep, 0x7F7F7F7Fu, w.H * 4, s);
-        hipLaunchKernelGGL(row_rep_insert_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, w.hash, B, w.hkeys, w.hrep, (int64_t)w.H - 1, w.pos);
+        hipLaunchKernelGGL(row_rep_clear_kernel, dim3((unsigned)((w.H + 255) / 256)), dim3(256), 0, s, w.hkeys, w.hrep, (int64_t)w.H);   // a kernel, not memsets: ncf_common.h
+        hipLaunchKernelGGL(dense_row_scan_kernel, dim3(wblocks), dim3(256), 0, s, um, ld, B, I, w.cnt, w.hkeys, w.hrep, (int64_t)w.H - 1, w.pos);
         hipLaunchKernelGGL(row_rep_verify_kernel, dim3(wblocks), dim3(256), 0, s, um, ld, B, I, w.hrep, w.pos, w.cnt, pair_row, keep_cnt);
     } else {
+        hipLaunchKernelGGL(dense_row_scan_kernel, dim3(wblocks), dim3(256), 0, s, um, ld, B, I, w.cnt, (unsigned long long*)nullptr, (int*)nullptr, (int64_t)0, (int64_t*)nullptr);
         hipLaunchKernelGGL(rows_self_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, w.cnt, pair_row, keep_cnt);
     }
     return check_launch("ncf_dense_csr_rows");

@@ -690,16 +690,15 @@ def dense_to_csr(user_matrix: torch.Tensor, share_rows: bool = True):
     B, I, ld = _rows2d(user_matrix, "user_matrix")
     dev = user_matrix.device
     pair_row = torch.empty(B, dtype=torch.int64, device=dev)
-    rowptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
     col = torch.empty(max(B * I, 1), dtype=torch.int32, device=dev)
     val = torch.empty(max(B * I, 1), dtype=torch.float32, device=dev)
     if B == 0:
-        return rowptr, col, val, pair_row
-    keep = torch.empty(B, dtype=torch.int64, device=dev)
+        return torch.zeros(1, dtype=torch.int64, device=dev), col, val, pair_row
+    rowptr = torch.empty(B + 1, dtype=torch.int64, device=dev)     # [0, counts...] from the kernels; the cumulative sum runs in place
     nbytes = lib.ncf_dense_csr_workspace_bytes(B)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    _check(lib.ncf_dense_csr_rows(_ptr(user_matrix), ld, B, I, 1 if share_rows else 0, _ptr(pair_row), _ptr(keep), _ptr(ws), nbytes, _stream(user_matrix)))
-    torch.cumsum(keep, 0, out=rowptr[1:])
+    _check(lib.ncf_dense_csr_rows(_ptr(user_matrix), ld, B, I, 1 if share_rows else 0, _ptr(pair_row), _ptr(rowptr), _ptr(ws), nbytes, _stream(user_matrix)))
+    torch.cumsum(rowptr, 0, out=rowptr)
     _check(lib.ncf_dense_csr_fill(_ptr(user_matrix), ld, B, I, _ptr(rowptr), _ptr(pair_row), _ptr(col), _ptr(val), _stream(user_matrix)))
     return rowptr, col, val, pair_row
 

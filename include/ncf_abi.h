@@ -408,15 +408,15 @@ int ncf_attn_tail(const float* dev_cand_emb, int64_t ldcand, int EA,
  * content_providers/dynamic_profiles_provider.py:55-71; one row for every candidate in webapp/backend.py:78-121) and keeps the
  * entries != 0 (models/attention_ncf.py:158).  Two calls around one cumulative sum the caller runs on the stream:
  *   ncf_dense_csr_rows  -> dev_pair_row[b] = the row pair b uses (the smallest pair index with an IDENTICAL row when share_rows != 0
- *                          — found by a row hash and verified element by element —, b itself otherwise) and dev_keep_cnt[b] = the
- *                          entries row b will list (0 for a row that shares another's)
- *   rowptr = [0, cumsum(dev_keep_cnt)]
+ *                          — found by a row hash and verified element by element —, b itself otherwise) and dev_rowptr (B + 1) =
+ *                          [0, entries row 0 will list, entries row 1 will list, ...] (0 for a row that shares another's)
+ *   an inclusive cumulative sum over dev_rowptr, IN PLACE, makes it the CSR's rowptr
  *   ncf_dense_csr_fill  -> the representatives' (col, val) in column order at rowptr[b]; dev_col / dev_val must hold rowptr[B]
  *                          entries (B * I is always enough).
  * -0.0 counts as 0 (unrated); a row containing NaN never shares.  workspace: ncf_dense_csr_workspace_bytes(B), 16-byte aligned. */
 size_t ncf_dense_csr_workspace_bytes(int64_t B);
 int ncf_dense_csr_rows(const float* dev_user_matrix, int64_t ld, int64_t B, int64_t I, int share_rows,
-                       int64_t* dev_pair_row, int64_t* dev_keep_cnt, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
+                       int64_t* dev_pair_row, int64_t* dev_rowptr, void* dev_workspace, size_t workspace_bytes, ncf_stream_t stream);
 int ncf_dense_csr_fill(const float* dev_user_matrix, int64_t ld, int64_t B, int64_t I, const int64_t* dev_rowptr,
                        const int64_t* dev_pair_row, int32_t* dev_col, float* dev_val, ncf_stream_t stream);
 
