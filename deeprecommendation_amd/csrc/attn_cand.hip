@@ -352,6 +352,123 @@ __global__ __launch_bounds__(512, 4) void attn_cand_packed_kernel(const CandArgs
     }
 }
 
+// ---- small batches: the K range split over WORKGROUPS (packed weights) ----------------------------------------------------------
+// Every workgroup of the kernels above pulls the whole of Wi through its CU's L2 port (N1 = 128: 1 MB at ~70 GB/s = 15 us), however
+// few row tiles there are: at the reference's evaluation batch (512 rows = 32 tiles) 32 CUs do that while 224 idle (32.8 us).  Here
+// a row tile's K range is cut into KS pieces of 8 wave slices each (KS * tiles <= 256 workgroups): a workgroup ingests 1 / KS of Wi,
+// leaves its partial 16 x N1 tile in the workspace, and a second, short launch adds the KS partials in order (+ bias), writes emb,
+// and runs the second product (and the grouping workgroup).  Deterministic; another summation order than the one-launch forms.
+template <int N1>
+__global__ __launch_bounds__(512) void cand_splitk_kernel(const CandArgs a, float* __restrict__ part, int KS) {
+    constexpr int NWV = 8, TM = 16, NT = N1 / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * TM;
+    const int ks = blockIdx.y;
+    const int K = a.K, SF = K / 32;
+    const int slice = ks * NWV + wave, nsl = KS * NWV;
+    const int s_lo = (int)((int64_t)slice * SF / nsl), s_hi = (int)((int64_t)(slice + 1) * SF / nsl);
+    const int64_t m = row0 + i16 < a.B ? row0 + i16 : a.B - 1;
+    const float* xa = a.x + m * a.ldx + 4 * g4;                    // operand-order loads (16 rows x 64 B per instruction): one or two steps per wave
+    const f32x4* const wa = reinterpret_cast<const f32x4*>(a.Wi) + lane;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = s_lo; s < s_hi; ++s) {
+        f32x4 av[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) av[h] = *reinterpret_cast<const f32x4u*>(xa + 32 * s + 16 * h);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 w[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) w[h] = wa[(((int64_t)s * NT + nt) * 2 + h) * 64];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][j], w[h][j], acc[nt], 0, 0, 0);
+        }
+    }
+    if (slice == 0 && (K & 31)) {                                  // ragged end of K: guarded loads of x; the packed W is zero past K
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 32 * SF + 16 * h + 4 * g4 + j;
+                v[j] = k < K ? a.x[m * a.ldx + k] : 0.f;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 w = wa[(((int64_t)SF * NT + nt) * 2 + h) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], w[j], acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    float* const red = smem_f;                                     // [NWV][TM][N1]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(wave * TM + 4 * g4 + i) * N1 + 16 * nt + i16] = acc[nt][i];
+    __syncthreads();
+    float* const dst = part + ((int64_t)ks * gridDim.x + blockIdx.x) * (TM * N1);
+    for (int o = tid; o < TM * N1; o += 512) {
+        float v = red[o];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) v += red[w * TM * N1 + o];
+        dst[o] = v;
+    }
+}
+
+template <int N1>
+__global__ __launch_bounds__(512) void cand_finish_kernel(const CandArgs a, const float* __restrict__ part, int KS, int tiles) {
+    constexpr int NWV = 8, TM = 16, CES = N1 + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool grouping = a.pair_row != nullptr;
+    if (grouping && blockIdx.x == 0) {
+        int* lds = reinterpret_cast<int*>(smem_f);
+        if (a.R <= kGroupLdsRows)
+            group_small_body<true, 512>(a.pair_row, a.B, a.R, a.ppw, a.gcounts, a.gcursor, a.bad, a.grp_ptr, a.wg_ptr, a.pair_ids, a.wg_row, lds);
+        else
+            group_small_body<false, 512>(a.pair_row, a.B, a.R, a.ppw, a.gcounts, a.gcursor, a.bad, a.grp_ptr, a.wg_ptr, a.pair_ids, a.wg_row, lds);
+        return;
+    }
+    const int tile = (int)blockIdx.x - (grouping ? 1 : 0);
+    const int64_t row0 = (int64_t)tile * TM;
+    if (row0 >= a.B) return;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    float* const ce = smem_f;                                      // [TM][CES]  the cand_emb tile
+    for (int o = tid; o < TM * N1; o += 512) {
+        const int r = o / N1, c = o - r * N1;
+        float v = part[(int64_t)tile * (TM * N1) + o];
+        for (int k = 1; k < KS; ++k) v += part[((int64_t)k * tiles + tile) * (TM * N1) + o];   // pieces in K order
+        v += a.bi ? a.bi[c] : 0.f;
+        ce[r * CES + c] = v;
+        if (row0 + r < a.B) a.emb[(row0 + r) * a.ldemb + c] = v;
+    }
+    __syncthreads();
+    for (int ct = wave; ct < a.N2 / 16; ct += NWV) {
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+        const float* wrow = a.Wc + (int64_t)(16 * ct + i16) * N1 + 4 * g4;
+#pragma unroll
+        for (int kk = 0; kk < N1 / 16; ++kk) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ce + i16 * CES + 16 * kk + 4 * g4);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 16 * kk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc2, 0, 0, 0);
+        }
+        const float bv = a.b0 ? a.b0[16 * ct + i16] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = row0 + 4 * g4 + i;
+            if (m < a.B) a.pc[m * a.ldpc + 16 * ct + i16] = acc2[i] + bv;
+        }
+    }
+}
+
 }  // namespace ncf
 
 using namespace ncf;
@@ -363,6 +480,18 @@ extern "C" int ncf_attn_candidates_supported(int K, int N1, int N2) {
 extern "C" size_t ncf_attn_candidates_workspace_bytes(int64_t n_rows) { return (size_t)(2 * (n_rows > 0 ? n_rows : 0) + 1) * sizeof(int); }
 
 namespace {
+// pieces of the K range a row tile is cut into (packed form): 1 = one launch; 2..8 when the batch has at most 128 row tiles
+int cand_splitk_pieces(int64_t B) {
+    const int64_t tiles = (B + 15) / 16;
+    if (tiles < 1 || tiles > 128) return 1;
+    const int64_t ks = 256 / tiles;
+    return ks > 8 ? 8 : (int)ks;
+}
+size_t cand_partial_bytes(int64_t B, int N1) {
+    const int ks = cand_splitk_pieces(B);
+    return ks > 1 ? (size_t)ks * (size_t)((B + 15) / 16) * 16 * (size_t)N1 * sizeof(float) : 0;
+}
+
 int cand_launch(bool packed, const float* x, int64_t B, int64_t ldx, int K, const float* Wi, int64_t ldw, const float* bi, int N1,
                 const float* Wc, const float* b0, int N2, float* emb, int64_t ldemb, float* pc, int64_t ldpc,
                 const int64_t* pair_row, int64_t R, int pairs_per_wg, int64_t* grp_ptr, int64_t* pair_ids,
@@ -375,6 +504,13 @@ int cand_launch(bool packed, const float* x, int64_t B, int64_t ldx, int K, cons
     if (!x || !Wi || !Wc || !emb || !pc) return fail(NCF_EINVAL, "%s: null pointer", who);
     if (!aligned16(Wc)) return fail(NCF_EINVAL, "%s: Wc must be 16-byte aligned (contiguous (N2, N1))", who);
     if (packed && !aligned16(Wi)) return fail(NCF_EINVAL, "%s: the packed weights must be 16-byte aligned", who);
+    // packed form: [partial tiles of the split-K path | grouping ints]
+    const int KS = packed ? cand_splitk_pieces(B) : 1;
+    const size_t part_bytes = packed ? cand_partial_bytes(B, N1) : 0;
+    if (part_bytes && (!workspace || workspace_bytes < part_bytes || !aligned16(workspace)))
+        return fail(NCF_EWORKSPACE, "%s: workspace too small (ncf_attn_candidates_packed_workspace_bytes) or misaligned", who);
+    float* const part = (float*)workspace;
+    if (part_bytes) { workspace = (char*)workspace + part_bytes; workspace_bytes -= part_bytes; }
     CandArgs a{};
     a.x = x; a.Wi = Wi; a.bi = bi; a.Wc = Wc; a.b0 = b0; a.emb = emb; a.pc = pc;
     a.B = B; a.ldx = ldx; a.ldw = ldw; a.ldemb = ldemb; a.ldpc = ldpc; a.K = K; a.N2 = N2;
@@ -414,7 +550,21 @@ int cand_launch(bool packed, const float* x, int64_t B, int64_t ldx, int K, cons
         if (!raise((const void*)KERNEL, done)) return fail(NCF_EUNSUPPORTED, "%s: cannot reserve %zu bytes of LDS", who, lds);     \
         hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(512), lds, s, a);                                                           \
     }
-    if (packed) {
+    if (packed && KS > 1) {                                        // few row tiles: K range over workgroups, then a short finishing launch
+        const unsigned tiles = (unsigned)((B + 15) / 16);
+        const size_t lds_a = (size_t)8 * 16 * N1 * 4;
+        size_t lds_b = (size_t)16 * (N1 + 4) * 4;
+        if (pair_row && lds_grp > lds_b) lds_b = lds_grp;
+#define NCF_CAND_SPLITK(N)                                                                                                        \
+    {                                                                                                                             \
+        static std::atomic<unsigned long long> done{0};                                                                           \
+        if (!raise((const void*)cand_splitk_kernel<N>, done)) return fail(NCF_EUNSUPPORTED, "%s: cannot reserve %zu bytes of LDS", who, lds_a); \
+        hipLaunchKernelGGL(cand_splitk_kernel<N>, dim3(tiles, (unsigned)KS), dim3(512), lds_a, s, a, part, KS);                   \
+        hipLaunchKernelGGL(cand_finish_kernel<N>, dim3(blocks), dim3(512), lds_b, s, a, (const float*)part, KS, (int)tiles);      \
+    }
+        if (N1 == 64) NCF_CAND_SPLITK(64) else NCF_CAND_SPLITK(128)
+#undef NCF_CAND_SPLITK
+    } else if (packed) {
         if (N1 == 64) NCF_CAND_LAUNCH(attn_cand_packed_kernel<64>) else NCF_CAND_LAUNCH(attn_cand_packed_kernel<128>)
     } else {
         if (N1 == 64) NCF_CAND_LAUNCH(attn_cand_kernel<64>) else NCF_CAND_LAUNCH(attn_cand_kernel<128>)
@@ -443,6 +593,12 @@ extern "C" int ncf_attn_candidates_pack(const float* Wi, int64_t ldw, int K, int
     const int64_t n = (int64_t)S * (N1 / 16) * 512;
     hipLaunchKernelGGL(cand_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Wi, ldw, K, N1, S, packed);
     return check_launch("ncf_attn_candidates_pack");
+}
+
+/* workspace of ncf_attn_candidates_packed: the split-K path's partial tiles (batches of at most 128 row tiles) + the grouping's
+ * counters (n_rows < 0: no grouping) */
+extern "C" size_t ncf_attn_candidates_packed_workspace_bytes(int64_t B, int N1, int64_t n_rows) {
+    return cand_partial_bytes(B > 0 ? B : 0, N1) + (n_rows >= 0 ? ncf_attn_candidates_workspace_bytes(n_rows) : 0);
 }
 
 extern "C" int ncf_attn_candidates_packed(const float* x, int64_t B, int64_t ldx, int K, const float* Wi_packed, const float* bi, int N1,

@@ -78,6 +78,7 @@ SIGNATURES = {
     "ncf_attn_candidates": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_i64, _c_p, _c_i64,
                                      _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
     "ncf_attn_candidates_pack_floats": (_c_size, [_c_int, _c_int]),
+    "ncf_attn_candidates_packed_workspace_bytes": (_c_size, [_c_i64, _c_int, _c_i64]),
     "ncf_attn_candidates_pack": (_c_int, [_c_p, _c_i64, _c_int, _c_int, _c_p, _c_p]),
     "ncf_attn_candidates_packed": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_i64, _c_p, _c_i64,
                                             _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_size, _c_p, _c_p]),
@@ -796,13 +797,12 @@ class PackedCandidateWeight:
             raise TypeError("attn_candidates computes in fp32")
         self.N1, self.K, ldw = _rows2d(Wi, "Wi")
         self.src = Wi
-        # N1 = 128: the packed kernel holds half a step less in flight than the LDS-staged one and measured slower at the reference's
-        # evaluation batch (33.3 vs 29.7 us at B = 512): attn_candidates() takes the unpacked entry point there
+        # N1 = 128: the packed ONE-LAUNCH kernel holds half a step less in flight than the LDS-staged one and measured slower (33.3 vs
+        # 29.7 us): attn_candidates() takes the unpacked entry point there for batches above 2048 rows.  Up to 2048 rows (128 row
+        # tiles) the packed entry point cuts the K range over workgroups — the form for the reference's evaluation batch of 512.
         self.use_packed = self.N1 == 64
-        self.data = None
-        if self.use_packed:
-            self.data = torch.empty(lib.ncf_attn_candidates_pack_floats(self.K, self.N1), dtype=torch.float32, device=Wi.device)
-            _check(lib.ncf_attn_candidates_pack(_ptr(Wi), ldw, self.K, self.N1, _ptr(self.data), _stream(Wi)))
+        self.data = torch.empty(lib.ncf_attn_candidates_pack_floats(self.K, self.N1), dtype=torch.float32, device=Wi.device)
+        _check(lib.ncf_attn_candidates_pack(_ptr(Wi), ldw, self.K, self.N1, _ptr(self.data), _stream(Wi)))
 
 
 def attn_candidates(x: torch.Tensor, Wi, bi: Optional[torch.Tensor], Wc: torch.Tensor, b0: Optional[torch.Tensor],
@@ -813,8 +813,8 @@ def attn_candidates(x: torch.Tensor, Wi, bi: Optional[torch.Tensor], Wc: torch.T
     form, bit-identical results).  Shapes: attn_candidates_supported(); the fused grouping needs B, n_rows <= 32768."""
     lib = load_library()
     _dev(x, "x")
-    if isinstance(Wi, PackedCandidateWeight) and not Wi.use_packed:
-        Wi = Wi.src
+    if isinstance(Wi, PackedCandidateWeight) and not Wi.use_packed and x.shape[0] > 2048:
+        Wi = Wi.src                      # N1 = 128, large batch: the LDS-staged kernel (small batches: the packed form's split-K path)
     packed = isinstance(Wi, PackedCandidateWeight)
     if x.dtype != torch.float32 or (not packed and Wi.dtype != torch.float32) or Wc.dtype != torch.float32:
         raise TypeError("attn_candidates computes in fp32")
@@ -841,8 +841,11 @@ def attn_candidates(x: torch.Tensor, Wi, bi: Optional[torch.Tensor], Wc: torch.T
         pair_ids = torch.empty(max(B, 1), dtype=torch.int64, device=dev)
         wg_row = torch.empty((B + int(pairs_per_wg) - 1) // int(pairs_per_wg) + min(R, B) + 1, dtype=torch.int32, device=dev)
         nbytes = lib.ncf_attn_candidates_workspace_bytes(R)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         grp = Grouping(grp_ptr, pair_ids[:B], wg_ptr, wg_row)
+    if packed:
+        nbytes = lib.ncf_attn_candidates_packed_workspace_bytes(B, N1, R if pair_row is not None else -1)
+    if nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     tail = (_ptr(bi), N1, _ptr(Wc), _ptr(b0), N2, _ptr(emb), emb.stride(0), _ptr(pc), pc.stride(0), _ptr(pair_row), R, int(pairs_per_wg),
             _ptr(grp_ptr), _ptr(pair_ids), _ptr(wg_ptr), _ptr(wg_row), _ptr(ws), nbytes,
             _ptr(_oob_flag(dev)) if pair_row is not None else None, _stream(x))

@@ -440,8 +440,12 @@ int ncf_attn_candidates(const float* dev_x, int64_t B, int64_t ldx, int K,
 /* The same launch with ItemEmbeddings' weight PRE-PACKED in MFMA operand order (once per weight version: ncf_attn_candidates_pack
  * into ncf_attn_candidates_pack_floats(K, N1) floats, 16-byte aligned).  Every weight load is then one contiguous 1 KB run straight
  * into operand registers: the kernel fits two workgroups per CU, so the grouping workgroup runs beside a row tile instead of in front
- * of one.  Same arguments otherwise (no ldw), bit-identical emb / pc. */
+ * of one.  Same arguments otherwise (no ldw), bit-identical emb / pc — except for batches of at most 128 row tiles (B <= 2048), where a
+ * row tile's K range is cut over up to 8 workgroups (every CU ingests a piece of Wi instead of a few ingesting all of it) and a short
+ * second launch adds the pieces in order: deterministic, another summation order.  workspace (16-byte aligned):
+ * ncf_attn_candidates_packed_workspace_bytes(B, N1, n_rows or -1 without grouping). */
 size_t ncf_attn_candidates_pack_floats(int K, int N1);
+size_t ncf_attn_candidates_packed_workspace_bytes(int64_t B, int N1, int64_t n_rows);
 int ncf_attn_candidates_pack(const float* dev_Wi, int64_t ldw, int K, int N1, float* dev_packed, ncf_stream_t stream);
 int ncf_attn_candidates_packed(const float* dev_x, int64_t B, int64_t ldx, int K,
                                const float* dev_Wi_packed, const float* dev_bi, int N1,

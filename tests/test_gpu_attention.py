@@ -645,10 +645,12 @@ def test_attention_tail_kernel(gpu, E, B, nsplit):
 
 
 @pytest.mark.parametrize("B,K,N1,N2,users", [(4096, 2094, 64, 128, 64), (100, 2094, 128, 128, 7), (33, 96, 64, 16, 3), (17, 31, 64, 32, 17),
-                                               (512, 1000, 128, 256, 1), (1, 65, 64, 64, 1)])
+                                               (512, 1000, 128, 256, 1), (1, 65, 64, 64, 1), (2100, 300, 128, 64, 9), (2048, 77, 64, 128, 30),
+                                               (700, 2094, 64, 128, 11)])
 def test_attn_candidates_both_weight_forms(gpu, B, K, N1, N2, users):
     """ncf_attn_candidates / ncf_attn_candidates_packed (candidate ItemEmbeddings + candidate half of AttentionNet.0 + the listing of
-    the pairs by rated set in one launch): both against an fp64 product, bit-identical to each other, grouping = ncf_group_pairs_rows'.
+    the pairs by rated set in one launch): both against an fp64 product, bit-identical to each other where the packed form is one
+    launch (B > 2048; below that its K range is cut over workgroups), grouping = ncf_group_pairs_rows'.
     Ragged K (2094 = 65 * 32 + 14; 31 < one step), B not a multiple of the 16-row tile, both widths of ItemEmbeddings."""
     from deeprecommendation_amd import native
     g = torch.Generator().manual_seed(B + K)
@@ -663,17 +665,18 @@ def test_attn_candidates_both_weight_forms(gpu, B, K, N1, N2, users):
     p64 = e64 @ Wc.double().t() + b0.double()
     emb, pc, grp = native.attn_candidates(x, Wi, bi, Wc, b0, who, users, ppw)
     wpk = native.PackedCandidateWeight(Wi)
-    if not wpk.use_packed:                                      # N1 = 128: the wrapper prefers the unpacked kernel; test the packed one anyway
-        lib = native.load_library()
-        wpk.data = torch.empty(lib.ncf_attn_candidates_pack_floats(K, N1), dtype=torch.float32, device=gpu)
-        assert lib.ncf_attn_candidates_pack(Wi.data_ptr(), Wi.stride(0), K, N1, wpk.data.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
-        wpk.use_packed = True
+    wpk.use_packed = True                                       # N1 = 128, large batch: the wrapper prefers the unpacked kernel; test the packed one anyway
     emb2, pc2, grp2 = native.attn_candidates(x, wpk, bi, Wc, b0, who, users, ppw)
     emb3, pc3, none = native.attn_candidates(x, wpk, bi, Wc, b0)
     assert none is None
     assert_close(emb, e64.float())
     assert_close(pc, p64.float())
-    assert torch.equal(emb2, emb) and torch.equal(pc2, pc) and torch.equal(emb3, emb) and torch.equal(pc3, pc)
+    assert torch.equal(emb3, emb2) and torch.equal(pc3, pc2)    # with and without the grouping workgroup
+    if B > 2048:                                                # one launch: the LDS-staged form's k pairing, slices and order
+        assert torch.equal(emb2, emb) and torch.equal(pc2, pc)
+    else:                                                       # at most 128 row tiles: K range cut over workgroups, pieces added in order
+        assert_close(emb2, e64.float())
+        assert_close(pc2, p64.float())
     ref = native.group_pairs(who, users, ppw)
     n_wg = int(ref[2][-1])
     for gg in (grp, grp2):
