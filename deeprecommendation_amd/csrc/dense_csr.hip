@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void dense_row_compact_kernel(const float* __r
 
 using namespace ncf;
 
-extern "C" size_t ncf_dense_csr_table_slots(int64_t B) {
+static size_t ncf_dense_csr_table_slots(int64_t B) {       // slots of the row-hash table: a power of two >= 2 B
     size_t h = 1024;
     while ((int64_t)h < 2 * B) h <<= 1;
     return h;
