@@ -725,3 +725,40 @@ def test_dense_user_matrix_forward_replays_as_a_hip_graph(gpu):
             gr.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ref2)
+
+
+def test_attn_candidates_random_shapes(gpu):
+    """A seeded sweep over batch sizes, feature widths and layer widths through every form of the candidate kernel (LDS-staged, packed
+    one-launch, packed with the K range over workgroups): all within 1e-5 of an fp64 product, the pair lists complete."""
+    import random
+    from deeprecommendation_amd import native
+    rnd = random.Random(1234)
+    g = torch.Generator().manual_seed(99)
+    for case in range(24):
+        B = rnd.choice([1, 2, 15, 16, 17, 255, 512, 1000, 2047, 2048, 2049, 3000, 4097])
+        K = rnd.choice([1, 3, 31, 32, 33, 64, 100, 257, 1024, 2094])
+        N1 = rnd.choice([64, 128])
+        N2 = 16 * rnd.randint(1, 16)
+        users = rnd.choice([1, 2, 5, 64, max(1, B // 3)])
+        x = (torch.randn(B, K, generator=g) * (torch.rand(B, K, generator=g) < 0.3)).to(gpu)
+        Wi = (torch.randn(N1, K, generator=g) / max(K, 1) ** 0.5).to(gpu)
+        bi = (torch.randn(N1, generator=g) * 0.1).to(gpu)
+        Wc = (torch.randn(N2, N1, generator=g) / N1 ** 0.5).to(gpu)
+        b0 = (torch.randn(N2, generator=g) * 0.1).to(gpu)
+        who = torch.randint(0, users, (B,), generator=g).to(gpu)
+        e64 = x.double() @ Wi.double().t() + bi.double()
+        p64 = e64 @ Wc.double().t() + b0.double()
+        wpk = native.PackedCandidateWeight(Wi)
+        wpk.use_packed = True
+        for form, w in (("staged", Wi), ("packed", wpk)):
+            emb, pc, grp = native.attn_candidates(x, w, bi, Wc, b0, who, users, 32)
+            tag = f"case {case} {form}: B={B} K={K} N1={N1} N2={N2} users={users}"
+            try:
+                assert_close(emb, e64.float(), floor=1.0)          # 1e-5 of the largest output: signed inputs cancel
+                assert_close(pc, p64.float(), floor=1.0)
+            except AssertionError as exc:
+                raise AssertionError(tag) from exc
+            ids = grp[1]
+            assert ids.numel() == B and torch.equal(torch.sort(ids).values, torch.arange(B, device=gpu)), tag
+            assert torch.equal(who[ids], torch.sort(who).values), tag          # listed row by row
+    native.check_oob(gpu)
