@@ -53,7 +53,9 @@
 #define NCF_WS8_SPREAD 3      // B: one row DMA every this many layer-2 k-steps (0 = all DMAs at the head of the phase)
 #endif
 #ifndef NCF_WS8_DIST
-#define NCF_WS8_DIST 5        // D: row DMAs run this many units ahead of layer 1 (3 <= D < NU)
+#define NCF_WS8_DIST 3        // D: row DMAs run this many units ahead of layer 1 (3 <= D < NU).  Round 3, measured in one session (3 / 4 / 5): 65 536 pairs
+                              // 16.8 / 16.8 / 17.5-18.0 us, 131 072: 26.3 / 26.8 / 27.5, 262 144 to 4 M pairs equal within the noise (174 us at 1 M, 672-675 at 4 M):
+                              // a workgroup of config 5's own batch has 8 units, and the prologue waits for the ids of 2 D of them
 #endif
 
 namespace ncf {
