@@ -443,8 +443,12 @@ __global__ __launch_bounds__(512) void cand_finish_kernel(const CandArgs a, cons
     float* const ce = smem_f;                                      // [TM][CES]  the cand_emb tile
     for (int o = tid; o < TM * N1; o += 512) {
         const int r = o / N1, c = o - r * N1;
-        float v = part[(int64_t)tile * (TM * N1) + o];
-        for (int k = 1; k < KS; ++k) v += part[((int64_t)k * tiles + tile) * (TM * N1) + o];   // pieces in K order
+        float pv[8];                                               // all pieces requested at once (KS <= 8), added in K order
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pv[k] = part[((int64_t)(k < KS ? k : KS - 1) * tiles + tile) * (TM * N1) + o];
+        float v = pv[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v += k < KS ? pv[k] : 0.f;
         v += a.bi ? a.bi[c] : 0.f;
         ce[r * CES + c] = v;
         if (row0 + r < a.B) a.emb[(row0 + r) * a.ldemb + c] = v;
