@@ -57,15 +57,37 @@ __global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs a) {
             if (a.part && ATT_TAIL_DIAG != 1) {   // out = sum_s O_s e^(m_s - M) / sum_s l_s e^(m_s - M) + bias, slices in index order (attn_combine_kernel's order)
                 const float* p0 = a.part + b * a.nsplit * (int64_t)a.ldpart;
                 float M = -INFINITY;
-                for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, p0[(int64_t)s * a.ldpart]);
                 float L = 0.f;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int s = 0; s < a.nsplit; ++s) {
-                    const float* ps = p0 + (int64_t)s * a.ldpart;
-                    const float ms = ps[0];
-                    const float w = (ms == -INFINITY) ? 0.f : exp_le0(ms - M);
-                    L += ps[1] * w;
-                    acc += *reinterpret_cast<const f32x4*>(ps + kTailHead + 4 * cu) * w;
+                if (a.nsplit <= 8) {                       // the usual case: every slice's (m, l) and O chunk requested at once — a loop over
+                    const int ns = a.nsplit;               // a run-time count is a chain of dependent round trips
+                    f32x2 ml[8];
+                    f32x4 ov[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const float* ps = p0 + (int64_t)(s < ns ? s : ns - 1) * a.ldpart;
+                        ml[s] = *reinterpret_cast<const f32x2*>(ps);
+                        ov[s] = *reinterpret_cast<const f32x4*>(ps + kTailHead + 4 * cu);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) M = s < ns ? fmaxf(M, ml[s][0]) : M;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        if (s < ns) {
+                            const float w = (ml[s][0] == -INFINITY) ? 0.f : exp_le0(ml[s][0] - M);
+                            L += ml[s][1] * w;
+                            acc += ov[s] * w;
+                        }
+                    }
+                } else {
+                    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, p0[(int64_t)s * a.ldpart]);
+                    for (int s = 0; s < a.nsplit; ++s) {
+                        const float* ps = p0 + (int64_t)s * a.ldpart;
+                        const float ms = ps[0];
+                        const float w = (ms == -INFINITY) ? 0.f : exp_le0(ms - M);
+                        L += ps[1] * w;
+                        acc += *reinterpret_cast<const f32x4*>(ps + kTailHead + 4 * cu) * w;
+                    }
                 }
                 const float inv = L > 0.f ? 1.0f / L : 0.f;
                 f32x4 bias = {0.f, 0.f, 0.f, 0.f};
