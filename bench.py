@@ -297,6 +297,41 @@ def run_cfg2(args, ctx):
         ctx.barrier()
         elapsed = time.perf_counter() - t0
         native.check_oob(device)
+        # One GPU: the same steps also as HIP-graph launches of up to 32 steps over the resident index batches.  A step is one kernel
+        # either way; what the graph removes is the host's part of the FIRST step of the timed region (the GPU idles behind the
+        # synchronisation until Python has walked a whole forward) — 1-2 % of a 20-step run, nothing at 400 steps.
+        elapsed_eager, elapsed_graph, graph_err, steps_per_launch = elapsed, None, None, None
+        if world == 1 and os.environ.get("NCF_CFG2_NO_GRAPH") != "1":
+            try:
+                spl = next(pl for pl in range(min(args.steps, 32), 0, -1) if args.steps % pl == 0)
+                cur = torch.cuda.current_stream(device)
+                side = torch.cuda.Stream(device=device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    step(0)
+                cur.wait_stream(side)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    gouts = [step(k) for k in range(spl)]
+                gr.replay()
+                torch.cuda.synchronize()
+                if not torch.equal(gouts[spl - 1], step(spl - 1)):
+                    raise RuntimeError("graph replay differs from the eager step")
+                for _ in range(max(1, 300 // spl)):
+                    gr.replay()
+                ctx.barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps // spl):
+                    gr.replay()
+                ctx.barrier()
+                elapsed_graph = time.perf_counter() - t0
+                native.check_oob(device)
+                steps_per_launch = spl
+                del gr, gouts
+                elapsed = min(elapsed_eager, elapsed_graph)
+            except Exception as exc:   # noqa: BLE001 — never take the line down: the eager timing stands
+                graph_err = str(exc)
     elapsed = ctx.max_over_ranks(elapsed)
 
     # --- roofline of the dominant kernel (the kernels run on torch's current stream, so torch.cuda.Event brackets them)
@@ -419,7 +454,11 @@ def run_cfg2(args, ctx):
         "config": {"workload": "cfg2: BasicNCF 1M users x 100k items, emb_dim=64, batch=65536/GPU, fp32, MLP 128-256-128-1"
                                + (" [Zipf(1.05) user ids]" if ctxname == "cfg2zipf" else "")
                                + (" [first MLP layer FOLDED into 256-wide tables: 65 792 executed FLOP and 2068 B per pair]" if args.fold else ""),
-                   "parallelism": f"replicas x{world} (tables+MLP replicated, batch split, no collective)"},
+                   "parallelism": f"replicas x{world} (tables+MLP replicated, batch split, no collective)",
+                   "step_form": ("HIP-graph launches of %d steps over the resident index batches" % steps_per_launch
+                                 if elapsed_graph is not None and elapsed_graph <= elapsed_eager else "one forward per step, enqueued from Python"),
+                   "eager_ms_per_step": elapsed_eager / args.steps * 1e3,
+                   "graph_ms_per_step": None if elapsed_graph is None else elapsed_graph / args.steps * 1e3, "graph_error": graph_err},
         "roofline": {"kernel": "score_fused_f32_kernel<128,256,128>", "bound": "mfma", "achieved": achieved_tf,
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
                      "traffic": kt_f["traffic"], "us_per_launch": kt_f["us"], "us_per_launch_basis": kt_f["basis"],
