@@ -731,29 +731,27 @@ def run_cfg5(args, ctx):
                 for k in range(nb):
                     model(*batches[k])
             torch.cuda.current_stream(device).wait_stream(side)
+            # steps per launch: the largest divisor of the requested step count up to 32 (the batches are cycled)
+            spl = next(pl for pl in range(min(args.steps, 32), 0, -1) if args.steps % pl == 0)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                gouts = [model(*batches[k]) for k in range(nb)]
+                gouts = [model(*batches[k % nb]) for k in range(spl)]
             graph.replay()
             torch.cuda.synchronize()
-            for k in (0, nb - 1):
-                if not torch.equal(gouts[k], model(*batches[k])):
+            for k in (0, spl - 1):
+                if not torch.equal(gouts[k], model(*batches[k % nb])):
                     raise RuntimeError("graph replay differs from the eager step")
-            full = (args.steps // nb) * nb
 
-            def gstep(j):                      # steps 0 .. full-1 in graph launches of nb steps, the remainder one by one
-                if j < full:
-                    if j % nb == 0:
-                        graph.replay()
-                else:
-                    model(*batches[j % nb])
+            def gstep(j):                      # one graph launch per spl steps
+                if j % spl == 0:
+                    graph.replay()
             wall_g, _ = _time_steps(gstep, args.warmup, args.steps, ctx)
             wall_g = ctx.max_over_ranks(wall_g)
             forms["single_gpu_graph"] = {"ms_per_step": wall_g / args.steps * 1e3, "pairs_per_s": B * args.steps / wall_g,
-                                         "steps_per_graph_launch": nb}
+                                         "steps_per_graph_launch": spl}
             if wall_g < main_wall:
                 main_wall = wall_g
-                step_form = f"HIP graph of {nb} steps (the resident batches in order, no copies) per launch"
+                step_form = f"HIP graph of {spl} steps (the resident batches in order, no copies) per launch"
             del graph, gouts
         except Exception as exc:  # noqa: BLE001
             forms["single_gpu_graph"] = {"error": f"{type(exc).__name__}: {exc}"}
