@@ -327,6 +327,9 @@ def run_cfg2(args, ctx):
                 ctx.barrier()
                 elapsed_graph = time.perf_counter() - t0
                 native.check_oob(device)
+                if not (torch.equal(gouts[spl - 1], step(spl - 1)) and torch.equal(gouts[0], step(0))):   # still equal after the timed replays
+                    elapsed_graph = None
+                    raise RuntimeError("graph replay differs from the eager step after the timed replays")
                 steps_per_launch = spl
                 del gr, gouts
                 elapsed = min(elapsed_eager, elapsed_graph)

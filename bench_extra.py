@@ -351,6 +351,11 @@ def run_cfg3(args, ctx):
                     else:
                         step(j)
                 wall_graph_nb, _ = _time_steps(gstep_nb, args.warmup, args.steps)
+                # after the back-to-back replays of the timed region: the outputs still equal the eager step's (a replayed graph whose
+                # nodes lost their order shows only from the second replay on — the hipMemsetAsync trap of DESIGN §4.15)
+                if not (torch.equal(gouts[1], step(1)) and torch.equal(gouts[per_launch - 1], step((per_launch - 1) % nbt))):
+                    wall_graph_nb = None
+                    raise RuntimeError("graph replay differs from the eager step after the timed replays")
                 wall = min(wall, wall_graph_nb)
                 del gr, gouts
             except Exception as exc:   # noqa: BLE001
@@ -746,6 +751,9 @@ def run_cfg5(args, ctx):
                 if j % spl == 0:
                     graph.replay()
             wall_g, _ = _time_steps(gstep, args.warmup, args.steps, ctx)
+            for k in (0, spl - 1):               # still equal after the timed, back-to-back replays
+                if not torch.equal(gouts[k], model(*batches[k % nb])):
+                    raise RuntimeError("graph replay differs from the eager step after the timed replays")
             wall_g = ctx.max_over_ranks(wall_g)
             forms["single_gpu_graph"] = {"ms_per_step": wall_g / args.steps * 1e3, "pairs_per_s": B * args.steps / wall_g,
                                          "steps_per_graph_launch": spl}
