@@ -236,3 +236,62 @@ def test_resident_eval_attention_dataset(gpu, monkeypatch, att_dense, compact):
     frame.loc[7, "movieId"] = 5  # not a catalogue id
     with pytest.raises(IndexError):
         eval_model(m, DynamicPointwiseDataset(frame, prov), batch_size=64, device=gpu, resident=True)
+
+
+def test_back_to_back_graph_replays_of_every_model_family(gpu):
+    """A captured forward of each model family replayed a dozen times WITHOUT a synchronisation in between still equals the eager
+    forward (nodes of a replayed graph that lose their order show only from the second back-to-back replay on: the
+    hipMemsetAsync trap of DESIGN §4.15 — the library's launches are all kernel nodes now)."""
+    from deeprecommendation_amd.neural_collaborative_filtering.models.attention_ncf import AttentionNCF, SparseRatings
+    from deeprecommendation_amd.neural_collaborative_filtering.models.basic_ncf import BasicNCF
+    from deeprecommendation_amd.neural_collaborative_filtering.models.gnn_ncf import GraphData, GraphNCF
+    from deeprecommendation_amd.neural_collaborative_filtering.models.mf import MF
+    g = torch.Generator().manual_seed(8)
+
+    def replayed(fn):
+        with torch.no_grad():
+            ref = fn().clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                out = fn()
+            for _ in range(12):
+                gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+
+    torch.manual_seed(2)
+    bm = BasicNCF(item_dim=700, user_dim=3000, item_emb=64, user_emb=64, mlp_dense_layers=[256, 128]).eval().to(gpu)
+    u = torch.randint(0, 3000, (5000,), generator=g).to(gpu)
+    i = torch.randint(0, 700, (5000,), generator=g).to(gpu)
+    replayed(lambda: bm(u, i))
+    mf = MF(item_dim=700, user_dim=3000, item_emb=64, user_emb=64).eval().to(gpu)
+    replayed(lambda: mf(u, i))
+    # GraphNCF: propagation + readout
+    n_items, n_users = 60, 400
+    key = torch.unique(torch.randint(0, n_users, (5000,), generator=g) * n_items + torch.randint(0, n_items, (5000,), generator=g))
+    uu, ii = key // n_items + n_items, key % n_items
+    a = torch.randn(uu.numel(), generator=g)
+    graph = GraphData(user2item_edge_index=torch.stack([uu, ii]).to(gpu), item2user_edge_index=torch.stack([ii, uu]).to(gpu),
+                      user2item_edge_attr=a.to(gpu), item2user_edge_attr=a.clone().to(gpu), num_items=n_items, num_users=n_users)
+    gm = GraphNCF(item_dim=n_items, user_dim=n_users, num_gnn_layers=2, hetero=True, node_emb=64, mlp_dense_layers=[128]).eval().to(gpu)
+    gu = (torch.randint(0, n_users, (1000,), generator=g) + n_items).to(gpu)
+    gi = torch.randint(0, n_items, (1000,), generator=g).to(gpu)
+    replayed(lambda: gm(graph, gu, gi))
+    # AttentionNCF on provider-style shared-row ratings (the cfg 3 path: candidate kernel + grouping, entry-split attention, tail)
+    I, F, B, users = 300, 96, 2048, 16
+    am = AttentionNCF(item_dim=F, item_emb=64, user_emb=64, att_dense=128, mlp_dense_layers=[256, 128]).eval().to(gpu)
+    rated = (torch.rand(I, F, generator=g) < 0.2).float().to(gpu)
+    counts = torch.randint(20, 150, (users,), generator=g)
+    rowptr = torch.zeros(users + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    col = torch.cat([torch.randperm(I, generator=g)[:int(c)].sort().values for c in counts]).to(torch.int32)
+    val = torch.randint(1, 11, (int(rowptr[-1]),), generator=g).float() * 0.5 - 2.9
+    r = SparseRatings(rowptr.to(gpu), col.to(gpu), val.to(gpu), I, pair_row=torch.randint(0, users, (B,), generator=g).to(gpu))
+    cand = rated[torch.randint(0, I, (B,), generator=g).to(gpu)].contiguous()
+    replayed(lambda: am(cand, rated, r))
