@@ -203,7 +203,15 @@ def _check(rc: int):
         raise NativeError(rc, load_library().ncf_last_error().decode())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: torch.Tensor) -> int:
+    """torch's current stream on t's device as a raw hipStream_t (every launch of the library goes there).  The raw accessor costs
+    0.3 us where torch.cuda.current_stream() builds a Stream object (2.3 us, five times per AttentionNCF forward)."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return _raw_stream(idx if idx is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

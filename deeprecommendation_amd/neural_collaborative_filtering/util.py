@@ -52,22 +52,24 @@ def load_model(file, ModelClass=None, map_location="cpu", **kargs):
     return model
 
 
-def _iter_params(module: nn.Module):
-    for p in module._parameters.values():
-        if p is not None:
-            yield p
-    for child in module._modules.values():
-        if child is not None:
-            yield from _iter_params(child)
-
-
 def params_version(module: nn.Module) -> tuple:
     """Cheap fingerprint of a module's parameters: changes whenever a parameter is updated in place, re-assigned
     or moved (host and device allocations share one address space, so the address covers the device).  Used to
     invalidate the derived inference tensors (embedding tables, packed MLP weights).  Walks ``_parameters`` /
     ``_modules`` directly: ``module.parameters()`` builds names and hashes every tensor into a memo set, which made this
     the largest single host cost of a forward (a shared submodule is simply visited twice here)."""
-    return tuple((p.data_ptr(), p._version) for p in _iter_params(module))
+    out = []
+    stack = [module]
+    while stack:                                   # an explicit stack: the recursive generator cost 60 frames per forward
+        m = stack.pop()
+        for p in m._parameters.values():
+            if p is not None:
+                out.append(p.data_ptr())
+                out.append(p._version)
+        for child in m._modules.values():
+            if child is not None:
+                stack.append(child)
+    return tuple(out)
 
 
 def use_native(module: nn.Module, *tensors) -> bool:
