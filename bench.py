@@ -297,13 +297,17 @@ def run_cfg2(args, ctx):
         ctx.barrier()
         elapsed = time.perf_counter() - t0
         native.check_oob(device)
-        # One GPU: the same steps also as HIP-graph launches of up to 32 steps over the resident index batches.  A step is one kernel
-        # either way; what the graph removes is the host's part of the FIRST step of the timed region (the GPU idles behind the
-        # synchronisation until Python has walked a whole forward) — 1-2 % of a 20-step run, nothing at 400 steps.
-        elapsed_eager, elapsed_graph, graph_err, steps_per_launch = elapsed, None, None, None
-        if world == 1 and os.environ.get("NCF_CFG2_NO_GRAPH") != "1":
-            try:
-                spl = next(pl for pl in range(min(args.steps, 32), 0, -1) if args.steps % pl == 0)
+        # The same steps also as HIP-graph launches of up to 32 steps over the resident index batches (every rank its own graph: replicas
+        # share nothing).  A step is one kernel either way; what the graph removes is the host's part of the FIRST step of the timed
+        # region (the GPU idles behind the synchronisation until Python has walked a whole forward) — 3-7 % of a 20-step run, nothing
+        # at 400 steps.  With several ranks every decision below is taken collectively (a rank that could not capture takes all of them
+        # back to the eager figure), so the ranks never disagree on the number of barriers.
+        elapsed_eager = ctx.max_over_ranks(elapsed)
+        elapsed_graph, graph_err, steps_per_launch = None, None, None
+        if os.environ.get("NCF_CFG2_NO_GRAPH") != "1":
+            gr = gouts = None
+            spl = next(pl for pl in range(min(args.steps, 32), 0, -1) if args.steps % pl == 0)
+            try:                                   # capture: no collective in here
                 cur = torch.cuda.current_stream(device)
                 side = torch.cuda.Stream(device=device)
                 side.wait_stream(cur)
@@ -318,6 +322,10 @@ def run_cfg2(args, ctx):
                 torch.cuda.synchronize()
                 if not torch.equal(gouts[spl - 1], step(spl - 1)):
                     raise RuntimeError("graph replay differs from the eager step")
+            except Exception as exc:   # noqa: BLE001 — never take the line down: the eager timing stands
+                graph_err = str(exc)
+                gr = None
+            if ctx.max_over_ranks(0.0 if gr is not None else 1.0) == 0.0:      # every rank has its graph
                 for _ in range(max(1, 300 // spl)):
                     gr.replay()
                 ctx.barrier()
@@ -325,17 +333,23 @@ def run_cfg2(args, ctx):
                 for _ in range(args.steps // spl):
                     gr.replay()
                 ctx.barrier()
-                elapsed_graph = time.perf_counter() - t0
-                native.check_oob(device)
-                if not (torch.equal(gouts[spl - 1], step(spl - 1)) and torch.equal(gouts[0], step(0))):   # still equal after the timed replays
-                    elapsed_graph = None
-                    raise RuntimeError("graph replay differs from the eager step after the timed replays")
-                steps_per_launch = spl
-                del gr, gouts
-                elapsed = min(elapsed_eager, elapsed_graph)
-            except Exception as exc:   # noqa: BLE001 — never take the line down: the eager timing stands
-                graph_err = str(exc)
-    elapsed = ctx.max_over_ranks(elapsed)
+                local = time.perf_counter() - t0
+                still = True
+                try:
+                    native.check_oob(device)
+                    still = bool(torch.equal(gouts[spl - 1], step(spl - 1)) and torch.equal(gouts[0], step(0)))   # after the timed replays
+                except Exception as exc:   # noqa: BLE001
+                    still, graph_err = False, str(exc)
+                if not still and graph_err is None:
+                    graph_err = "graph replay differs from the eager step after the timed replays"
+                bad = ctx.max_over_ranks(0.0 if still else 1.0)
+                local = ctx.max_over_ranks(local)
+                if bad == 0.0:
+                    elapsed_graph, steps_per_launch = local, spl
+            elif graph_err is None:
+                graph_err = "another rank could not capture its graph"
+            del gr, gouts
+    elapsed = elapsed_eager if elapsed_graph is None else min(elapsed_eager, elapsed_graph)
 
     # --- roofline of the dominant kernel (the kernels run on torch's current stream, so torch.cuda.Event brackets them)
     packed = model._packed_mlp()
