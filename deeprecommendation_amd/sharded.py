@@ -178,7 +178,11 @@ class RowShardedTable:
         self.overflow = torch.zeros(1, dtype=torch.int32, device=self.local.device)
         # statistics of the bounded exchange since the last check(), kept on the device (read by check()): ids asked for,
         # distinct ids listed (= rows that had to travel or be gathered locally), of which for OTHER ranks, lookups
-        self._stat = torch.zeros(4, dtype=torch.int64, device=self.local.device)
+        # statistics of the bounded lookups: ids listed per owner accumulate on the device (ONE small add per lookup, no read);
+        # what the host knows anyway (ids asked, lookups) is counted on the host
+        self._listed = torch.zeros(max(self.world, 1), dtype=torch.int64, device=self.local.device)
+        self._asked = 0
+        self._lookups = 0
 
     @staticmethod
     def shard_bounds(total_rows: int, world: int, rank: int):
@@ -288,12 +292,9 @@ class RowShardedTable:
             else:
                 buf.rows_out.zero_()
         self.comm.all_to_all(buf.rows_in, buf.rows_out)     # exchange #2: W x cap rows back, equal splits
-        # statistics, on the device (no read): ids asked, ids listed, of which remote, lookups
-        listed = buf.counts[:W].to(torch.int64).clamp(max=cap)
-        self._stat[0] += idx.numel()
-        self._stat[1] += listed.sum()
-        self._stat[2] += listed.sum() - listed[self.rank]
-        self._stat[3] += 1
+        self._listed.add_(buf.counts[:W].clamp(max=cap))   # per owner, on the device (no read); eight tiny launches did this before
+        self._asked += idx.numel()
+        self._lookups += 1
         return buf.rows_in, buf.slot[:idx.numel()]
 
     def _flags(self):
@@ -311,9 +312,12 @@ class RowShardedTable:
 
     def wire_stats(self, reset: bool = True) -> dict:
         """Traffic of the bounded lookups since the last call (one host read): what travelled and how much of it was padding."""
-        asked, listed, remote, lookups = (int(v) for v in self._stat.tolist())
+        per_owner = self._listed.tolist()
+        asked, lookups, listed = self._asked, self._lookups, int(sum(per_owner))
+        remote = listed - int(per_owner[self.rank]) if self.world > 1 else 0
         if reset:
-            self._stat.zero_()
+            self._listed.zero_()
+            self._asked = self._lookups = 0
         E, elt = self.local.shape[1], self.local.element_size()
         cap = self.cap or 0
         shipped_rows = lookups * (self.world - 1) * cap
