@@ -805,10 +805,10 @@ class PackedCandidateWeight:
             raise TypeError("attn_candidates computes in fp32")
         self.N1, self.K, ldw = _rows2d(Wi, "Wi")
         self.src = Wi
-        # N1 = 128: the packed ONE-LAUNCH kernel holds half a step less in flight than the LDS-staged one and measured slower (33.3 vs
-        # 29.7 us): attn_candidates() takes the unpacked entry point there for batches above 2048 rows.  Up to 2048 rows (128 row
-        # tiles) the packed entry point cuts the K range over workgroups — the form for the reference's evaluation batch of 512.
-        self.use_packed = self.N1 == 64
+        # Both widths take the packed entry point at every batch size: measured (tools/ab_cand.py, us per call incl. the grouping;
+        # LDS-staged -> packed): N1 = 64: 4096 rows 25.1 -> 20.5, 16 384 rows 96.7 -> 74.0; N1 = 128: 512 rows 29.3 -> 22.2 (K range
+        # over workgroups), 4096 rows 41.3 -> 38.6, 16 384 rows 159.0 -> 141.5.  ``use_packed = False`` selects the LDS-staged kernel.
+        self.use_packed = True
         self.data = torch.empty(lib.ncf_attn_candidates_pack_floats(self.K, self.N1), dtype=torch.float32, device=Wi.device)
         _check(lib.ncf_attn_candidates_pack(_ptr(Wi), ldw, self.K, self.N1, _ptr(self.data), _stream(Wi)))
 
@@ -821,8 +821,8 @@ def attn_candidates(x: torch.Tensor, Wi, bi: Optional[torch.Tensor], Wc: torch.T
     form, bit-identical results).  Shapes: attn_candidates_supported(); the fused grouping needs B, n_rows <= 32768."""
     lib = load_library()
     _dev(x, "x")
-    if isinstance(Wi, PackedCandidateWeight) and not Wi.use_packed and x.shape[0] > 2048:
-        Wi = Wi.src                      # N1 = 128, large batch: the LDS-staged kernel (small batches: the packed form's split-K path)
+    if isinstance(Wi, PackedCandidateWeight) and not Wi.use_packed:
+        Wi = Wi.src
     packed = isinstance(Wi, PackedCandidateWeight)
     if x.dtype != torch.float32 or (not packed and Wi.dtype != torch.float32) or Wc.dtype != torch.float32:
         raise TypeError("attn_candidates computes in fp32")

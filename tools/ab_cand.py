@@ -53,6 +53,7 @@ def case(B=4096, K=2094, N1=64, N2=128, users=64, ppw=32):
     t_new = per_launch(lambda: native.attn_candidates(x, Wi, bi, Wc, b0, who, users, ppw))
     t_new_ng = per_launch(lambda: native.attn_candidates(x, Wi, bi, Wc, b0))
     wpk = native.PackedCandidateWeight(Wi)
+    wpk.use_packed = True                  # also where the wrapper would pick the LDS-staged kernel (N1 = 128, large batches)
     emb3, pc3, grp3 = native.attn_candidates(x, wpk, bi, Wc, b0, who, users, ppw)
     t_pk = per_launch(lambda: native.attn_candidates(x, wpk, bi, Wc, b0, who, users, ppw))
     t_pk_ng = per_launch(lambda: native.attn_candidates(x, wpk, bi, Wc, b0))
@@ -93,6 +94,9 @@ if __name__ == "__main__":
     case()
     case(B=4100, K=2094)
     case(B=512, K=2094, N1=128, N2=128, users=40)
+    case(B=4096, K=2094, N1=128, N2=128, users=64)
+    case(B=16384, K=2094, N1=128, N2=128, users=64)
+    case(B=16384, K=2094, N1=64, N2=128, users=64)
     case(B=4096, K=1030)
     case(B=8192, K=2094)
     case(B=333, K=50, N1=64, N2=16, users=7)
