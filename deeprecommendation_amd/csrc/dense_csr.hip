@@ -46,11 +46,17 @@ __global__ __launch_bounds__(256) void dense_row_scan_kernel(const float* __rest
     const float* row = um + b * ld;
     int n = 0;
     uint64_t h = 0;
-    for (int64_t c = lane; c < I; c += 64) {
-        const float v = row[c];
-        if (v != 0.f) {                                       // attention_ncf.py:158 — an entry that is exactly 0 (or -0) is unrated
-            ++n;
-            h += dmix64(((uint64_t)c << 32) | (uint64_t)__float_as_uint(v));   // commutative: a set hash of (column, value)
+    constexpr int U = 8;                                      // U loads in flight per lane: a plain loop over a run-time I is a chain of round trips
+    for (int64_t c0 = lane; c0 < I; c0 += 64 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = c0 + 64 * u < I ? row[c0 + 64 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (v[u] != 0.f) {                                // attention_ncf.py:158 — an entry that is exactly 0 (or -0) is unrated
+                ++n;
+                h += dmix64(((uint64_t)(c0 + 64 * u) << 32) | (uint64_t)__float_as_uint(v[u]));   // commutative: a set hash of (column, value)
+            }
         }
     }
 #pragma unroll
@@ -90,9 +96,17 @@ __global__ __launch_bounds__(256) void row_rep_verify_kernel(const float* __rest
         const float* r0 = um + b * ld;
         const float* r1 = um + rep * ld;
         bool same = true;
-        for (int64_t c = lane; c < I; c += 64) {
-            const float x = r0[c], y = r1[c];
-            same &= (x == y);                                  // -0 == 0; a NaN is never equal: such a row represents itself
+        constexpr int U = 4;
+        for (int64_t c0 = lane; c0 < I; c0 += 64 * U) {
+            float x[U], y[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = c0 + 64 * u < I;
+                x[u] = in ? r0[c0 + 64 * u] : 0.f;
+                y[u] = in ? r1[c0 + 64 * u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) same &= (x[u] == y[u]);    // -0 == 0; a NaN is never equal: such a row represents itself
         }
         if (!__all(same)) rep = b;                             // a hash collision between different rows: no sharing for this one
     }
@@ -117,17 +131,24 @@ __global__ __launch_bounds__(256) void dense_row_compact_kernel(const float* __r
     if (b >= B || pair_row[b] != b) return;                   // wave-uniform
     const float* row = um + b * ld;
     int64_t w = rowptr[b];
-    for (int64_t c0 = 0; c0 < I; c0 += 64) {                   // column order: a ballot ranks the wave's non-zero entries
-        const int64_t c = c0 + lane;
-        const float v = c < I ? row[c] : 0.f;
-        const bool nz = v != 0.f;
-        const unsigned long long m = __ballot(nz);
-        if (nz) {
-            const int64_t k = w + __popcll(m & ((1ull << lane) - 1ull));
-            col[k] = (int32_t)c;
-            val[k] = v;
+    constexpr int U = 8;
+    for (int64_t cb = 0; cb < I; cb += 64 * U) {               // U blocks of 64 columns loaded at once, then ranked in column order
+        float vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vv[u] = cb + 64 * u + lane < I ? row[cb + 64 * u + lane] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                          // a ballot ranks the wave's non-zero entries
+            const int64_t c = cb + 64 * u + lane;
+            const float v = vv[u];
+            const bool nz = v != 0.f;
+            const unsigned long long m = __ballot(nz);
+            if (nz) {
+                const int64_t k = w + __popcll(m & ((1ull << lane) - 1ull));
+                col[k] = (int32_t)c;
+                val[k] = v;
+            }
+            w += __popcll(m);
         }
-        w += __popcll(m);
     }
 }
 
