@@ -88,8 +88,9 @@ SIGNATURES = {
                                         _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_i64, _c_int, _c_p, _c_p,
                                         _c_i64, _c_int, _c_int, _c_p, _c_size, _c_p]),
     "ncf_attn_tail_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
+    "ncf_attn_tail_pack_weight": (_c_int, [_c_p, _c_int, _c_int, _c_p, _c_p]),
     "ncf_attn_tail": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_int, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int,
-                               _c_p, ctypes.c_float, _c_p, _c_i64, _c_p]),
+                               _c_p, ctypes.c_float, _c_int, _c_p, _c_i64, _c_p]),
     "ncf_edge_softmax_csr": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "ncf_edge_softmax_segmented_workspace_bytes": (_c_size, [_c_i64, _c_i64]),
     "ncf_edge_softmax_segmented": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_size, _c_p]),
@@ -875,12 +876,32 @@ def attn_tail_supported(EA: int, UE: int, N1: int, N2: int) -> bool:
     return bool(load_library().ncf_attn_tail_supported(int(EA), int(UE), int(N1), int(N2)))
 
 
+class PackedTailWeight:
+    """A hidden layer's (N, K) weight of the tail MLP in MFMA operand order (ncf_attn_tail_pack_weight), built once per weight version."""
+
+    def __init__(self, W: torch.Tensor):
+        lib = load_library()
+        _dev(W, "W")
+        if W.dtype != torch.float32 or W.dim() != 2 or not W.is_contiguous():
+            raise TypeError("PackedTailWeight takes a contiguous fp32 (N, K) weight")
+        self.shape = tuple(W.shape)
+        self.data = torch.empty_like(W)
+        _check(lib.ncf_attn_tail_pack_weight(_ptr(W), int(W.shape[0]), int(W.shape[1]), _ptr(self.data), _stream(W)))
+
+    def is_contiguous(self):
+        return True
+
+
 def attn_tail(cand_emb: torch.Tensor, user, ubias: Optional[torch.Tensor], W1, b1, W2, b2, w3, b3: float) -> torch.Tensor:
     """ncf_attn_tail: merge of the attention partials (``user`` an AttnPartials; ``ubias`` = UserEmbeddings' bias) or finished user
-    embeddings (``user`` a (B, UE) tensor, ``ubias`` None), cat(candidate_emb, user_emb), MLP -> (B, 1)."""
+    embeddings (``user`` a (B, UE) tensor, ``ubias`` None), cat(candidate_emb, user_emb), MLP -> (B, 1).  W1 / W2: both tensors in
+    the reference's row-major layout, or both PackedTailWeight (the faster form, bit-identical)."""
     lib = load_library()
     _dev(cand_emb, "cand_emb")
     B, EA, ldc = _rows2d(cand_emb, "cand_emb")
+    packed = isinstance(W1, PackedTailWeight)
+    if packed != isinstance(W2, PackedTailWeight):
+        raise TypeError("attn_tail: W1 and W2 must both be packed or both be plain tensors")
     N1, N2 = int(W1.shape[0]), int(W2.shape[0])
     out = torch.empty((B, 1), dtype=torch.float32, device=cand_emb.device)
     if isinstance(user, AttnPartials):
@@ -890,8 +911,9 @@ def attn_tail(cand_emb: torch.Tensor, user, ubias: Optional[torch.Tensor], W1, b
         part, ns, uptr = None, 1, user
     if W1.shape[1] != EA + UE or W2.shape[1] != N1 or w3.numel() != N2 or not (W1.is_contiguous() and W2.is_contiguous() and w3.is_contiguous()):
         raise ValueError("attn_tail: MLP weights do not match cat(candidate_emb, user_emb)")
-    _check(lib.ncf_attn_tail(_ptr(cand_emb), ldc, EA, _ptr(part), ns, _ptr(uptr), ldu, UE, _ptr(ubias), _ptr(W1), _ptr(b1), N1, _ptr(W2), _ptr(b2), N2,
-                             _ptr(w3), float(b3), _ptr(out), B, _stream(cand_emb)))
+    w1p, w2p = (W1.data, W2.data) if packed else (W1, W2)
+    _check(lib.ncf_attn_tail(_ptr(cand_emb), ldc, EA, _ptr(part), ns, _ptr(uptr), ldu, UE, _ptr(ubias), _ptr(w1p), _ptr(b1), N1, _ptr(w2p), _ptr(b2), N2,
+                             _ptr(w3), float(b3), 1 if packed else 0, _ptr(out), B, _stream(cand_emb)))
     return out
 
 

@@ -218,8 +218,9 @@ class AttentionNCF(_ScoringMixin, NCF):
                   and native.attn_tail_supported(IE, UE, lins[0].out_features, lins[1].out_features))
             cache["tail_mlp"] = None
             if ok:
-                cache["tail_mlp"] = (lins[0].weight.detach().contiguous(), lins[0].bias.detach().contiguous(),
-                                     lins[1].weight.detach().contiguous(), lins[1].bias.detach().contiguous(),
+                # the two hidden layers' weights packed once per weight version in MFMA operand order (coalesced weight loads in the kernel)
+                cache["tail_mlp"] = (native.PackedTailWeight(lins[0].weight.detach().contiguous()), lins[0].bias.detach().contiguous(),
+                                     native.PackedTailWeight(lins[1].weight.detach().contiguous()), lins[1].bias.detach().contiguous(),
                                      lins[2].weight.detach().reshape(-1).contiguous(), float(lins[2].bias.detach().item()))
         return cache["tail_mlp"]
 

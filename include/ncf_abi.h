@@ -394,14 +394,17 @@ int ncf_attn_forward_split(int mode,
  * (ncf_attn_forward_split with merge = 0: dev_part = its workspace, (B, nsplit, UE + 4) floats — [m, l, -, -, O...]) into the user
  * embeddings (+ dev_ubias = UserEmbeddings' bias), cat(candidate_emb, user_emb) (:219), then the MLP of util.py:5-18
  * (EA + UE -> N1 -> N2 -> 1, ReLU between, none after the last).  dev_part == NULL: dev_user holds finished (B, UE) rows.
- * Weights in the reference's own layout: W1 (N1, EA + UE), W2 (N2, N1) row-major, w3 (N2).  Replaces attn_combine + the fused
- * scoring kernel for evaluation batches (16 pairs per workgroup instead of 32: twice the workgroups).
+ * Weights: W1 (N1, EA + UE), W2 (N2, N1), w3 (N2) — weights_packed = 0: W1 / W2 in the reference's own row-major layout;
+ * weights_packed = 1: each packed once per weight version by ncf_attn_tail_pack_weight (MFMA operand order: a wave's weight load is
+ * one contiguous 1 KB run instead of 16 rows x 64 bytes — 12.8 -> 9.8 us at BASELINE config 3; bit-identical results).  Replaces
+ * attn_combine + the fused scoring kernel for evaluation batches (16 pairs per workgroup instead of 32: twice the workgroups).
  * Shapes: ncf_attn_tail_supported (EA = UE in {64, 128}, N1 = 256, N2 = 128); else NCF_EUNSUPPORTED (use ncf_score_fused). */
 int ncf_attn_tail_supported(int EA, int UE, int N1, int N2);
+int ncf_attn_tail_pack_weight(const float* dev_W, int N, int K, float* dev_packed, ncf_stream_t stream);
 int ncf_attn_tail(const float* dev_cand_emb, int64_t ldcand, int EA,
                   const float* dev_part, int nsplit, const float* dev_user, int64_t lduser, int UE, const float* dev_ubias,
                   const float* dev_W1, const float* dev_b1, int N1, const float* dev_W2, const float* dev_b2, int N2,
-                  const float* dev_w3, float b3, float* dev_out, int64_t B, ncf_stream_t stream);
+                  const float* dev_w3, float b3, int weights_packed, float* dev_out, int64_t B, ncf_stream_t stream);
 
 /* Dense user_matrix -> CSR with shared rows, on the stream (no size is read by the host).  The reference passes AttentionNCF.forward a
  * dense (B, I) user_matrix in which a user's row is repeated for each of their samples (datasets/dynamic_datasets.py:24-40,

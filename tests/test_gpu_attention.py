@@ -642,6 +642,12 @@ def test_attention_tail_kernel(gpu, E, B, nsplit):
     out2 = native.attn_tail(cand, native.AttnPartials(ws, nsplit, E, B), ubias, W1, b1, W2, b2, w3, b3)
     assert_close(out2, mlp64(torch.cat((cand.double(), ue), 1)))
     assert torch.equal(out2, native.attn_tail(cand, native.AttnPartials(ws, nsplit, E, B), ubias, W1, b1, W2, b2, w3, b3))
+    # the hidden layers' weights packed in MFMA operand order (what the model passes): the same values in the same order, bit for bit
+    P1, P2 = native.PackedTailWeight(W1), native.PackedTailWeight(W2)
+    assert torch.equal(out2, native.attn_tail(cand, native.AttnPartials(ws, nsplit, E, B), ubias, P1, b1, P2, b2, w3, b3))
+    assert torch.equal(out, native.attn_tail(cand, user, None, P1, b1, P2, b2, w3, b3))
+    with pytest.raises(TypeError):
+        native.attn_tail(cand, user, None, P1, b1, W2, b2, w3, b3)
 
 
 @pytest.mark.parametrize("B,K,N1,N2,users", [(4096, 2094, 64, 128, 64), (100, 2094, 128, 128, 7), (33, 96, 64, 16, 3), (17, 31, 64, 32, 17),

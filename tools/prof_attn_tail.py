@@ -19,6 +19,8 @@ part = torch.randn(B, ns, E + 4, device=dev, generator=g)
 part[:, :, 1] = part[:, :, 1].abs() + 0.1
 ws = part.view(torch.uint8).view(-1)
 ub = torch.randn(E, device=dev, generator=g)
+if os.environ.get("AB_TAIL_PACKED", "1") == "1":      # what the model passes: the hidden layers' weights in MFMA operand order
+    W1, W2 = native.PackedTailWeight(W1), native.PackedTailWeight(W2)
 for _ in range(60):
     native.attn_tail(cand, native.AttnPartials(ws, ns, E, B), ub, W1, b1, W2, b2, w3, 0.1)
 torch.cuda.synchronize()
